@@ -1,0 +1,100 @@
+"""Host-side input plumbing: one-char tokenizer directory + synthetic line-crop batches.
+
+Reference behaviour restated (no reference code is imported here):
+  * tokenizer: WordLevel + NFKC + split-every-char, specials [UNK] [PAD] [CLS] [SEP] [MASK] = ids 0..4,
+    bos=[CLS], eos=[SEP]; adds NO BOS/EOS on encode  -- train_tokenizer_one_char.py:66-95,129-141
+  * dataset item: pixel_values fp32 [3,H,W] in [-1,1]; labels = tokenizer(text, max_length,
+    padding="max_length", truncation=True) int64 [max_length]  -- src/data/trocr_dataset.py:97-104,173-201
+  * synthetic batch recipe: BASELINE.md section 4 / SURVEY.md section 8(d)
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from .config import ModelConfig
+
+SPECIAL_TOKENS = ["[UNK]", "[PAD]", "[CLS]", "[SEP]", "[MASK]"]
+
+
+def synthetic_charset(n: int) -> list[str]:
+    """n distinct NFKC-stable CJK ideographs starting at U+4E00 (ids 5.. after the 5 specials)."""
+    import unicodedata
+    out, cp = [], 0x4E00
+    while len(out) < n:
+        ch = chr(cp)
+        if unicodedata.normalize("NFKC", ch) == ch:
+            out.append(ch)
+        cp += 1
+    return out
+
+
+def build_decoder_dir(path: str, cfg: ModelConfig, with_weights: bool = False) -> str:
+    """Create the local ``decoder_path`` directory the reference expects
+    (config.json + tokenizer files; scripts/train_trocr.py:31-36,88-89) for a synthetic charset
+    of ``cfg.vocab - 5`` characters.  Character ids are assigned in code-point order so the
+    mapping is reproducible without a corpus."""
+    from tokenizers import Regex, Tokenizer, decoders, normalizers, pre_tokenizers
+    from tokenizers.models import WordLevel
+
+    os.makedirs(path, exist_ok=True)
+    chars = synthetic_charset(cfg.vocab - len(SPECIAL_TOKENS))
+    vocab = {t: i for i, t in enumerate(SPECIAL_TOKENS)}
+    for c in chars:
+        vocab[c] = len(vocab)
+    tok = Tokenizer(WordLevel(vocab=vocab, unk_token="[UNK]"))
+    tok.normalizer = normalizers.Sequence([normalizers.NFKC()])
+    tok.pre_tokenizer = pre_tokenizers.Split(Regex(r"[\s\S]"), behavior="isolated")
+    tok.decoder = decoders.Sequence([])
+    tok.add_special_tokens(SPECIAL_TOKENS)
+    tok.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w", encoding="utf-8") as f:
+        json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "unk_token": "[UNK]", "pad_token": "[PAD]",
+                   "cls_token": "[CLS]", "sep_token": "[SEP]", "mask_token": "[MASK]",
+                   "bos_token": "[CLS]", "eos_token": "[SEP]", "do_lower_case": False}, f)
+    with open(os.path.join(path, "special_tokens_map.json"), "w", encoding="utf-8") as f:
+        json.dump({"unk_token": "[UNK]", "pad_token": "[PAD]", "cls_token": "[CLS]", "sep_token": "[SEP]",
+                   "mask_token": "[MASK]", "bos_token": "[CLS]", "eos_token": "[SEP]"}, f)
+    with open(os.path.join(path, "config.json"), "w", encoding="utf-8") as f:
+        json.dump(cfg.decoder_config_dict(), f, indent=1)
+    return path
+
+
+def synthetic_batch(cfg: ModelConfig, batch: int, label_len: int = 128, seed: int = 1,
+                    min_chars: int = 8, max_chars: int = 60):
+    """(pixel_values fp32 [B,3,H,W] ~ N(0,1), labels int64 [B,label_len]).
+
+    randn crops are what the reference smoke tests feed (scripts/test_trocr_setup.py:124);
+    labels: n ~ U{min..max} ids drawn from 5..V-1, PAD elsewhere, no BOS/EOS.
+    """
+    rng = np.random.default_rng(seed)
+    px = rng.standard_normal((batch, cfg.channels, cfg.image_h, cfg.image_w), dtype=np.float32)
+    labels = np.full((batch, label_len), cfg.pad_id, dtype=np.int64)
+    hi = min(max_chars, label_len)
+    lo = min(min_chars, hi)
+    for b in range(batch):
+        n = int(rng.integers(lo, hi + 1))
+        labels[b, :n] = rng.integers(5, cfg.vocab, size=n)
+    return px, labels
+
+
+class SyntheticLineDataset:
+    """Map-style dataset with the reference's item dict (src/data/trocr_dataset.py:196-201)."""
+
+    def __init__(self, cfg: ModelConfig, n: int, label_len: int = 128, seed: int = 1):
+        self.cfg, self.n, self.label_len, self.seed = cfg, n, label_len, seed
+        self._chars = None
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __getitem__(self, i: int):
+        import torch
+        px, lab = synthetic_batch(self.cfg, 1, self.label_len, seed=self.seed * 1_000_003 + i)
+        if self._chars is None:
+            self._chars = synthetic_charset(self.cfg.vocab - len(SPECIAL_TOKENS))
+        text = "".join(self._chars[t - 5] for t in lab[0] if t != self.cfg.pad_id)
+        return {"pixel_values": torch.from_numpy(px[0]), "labels": torch.from_numpy(lab[0]),
+                "text": text, "image_path": f"synthetic://{i}"}

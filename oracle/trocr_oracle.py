@@ -1,0 +1,271 @@
+"""ORACLE (test infrastructure -- never imported by the product path).
+
+CPU restatement, in plain torch ops (fp32 by default, fp64 on request), of the reference's
+TrOCR training path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module.
+
+Parity status: PINNED for forward / loss / gradients by ``tests/golden/*.npz``, which were
+generated in the build container by importing the reference ``TrOCRModel``
+(/root/reference/src/models/trocr_model.py, with the three import shims of SURVEY.md section
+8(c)) -- see ``tools/gen_golden.py``.  UNPINNED: ``radam_schedulefree_step`` (schedulefree==1.4.1
+source absent from the container; restated from the published algorithm) and the DDP
+mean-of-rank-means semantics (Lightning absent).
+
+Every function cites the reference lines it follows.  "HF:" = transformers
+(models/vit/modeling_vit.py, models/roberta/modeling_roberta.py), whose layers the reference
+instantiates at src/models/trocr_model.py:147-149 and :231.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _gelu(x):  # erf GELU: ViTConfig.hidden_act="gelu" default; RobertaConfig hidden_act="gelu"
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _heads(x, nh):  # [B,S,H] -> [B,nh,S,d]   (HF modeling_vit.py:212-217)
+    B, S, H = x.shape
+    return x.view(B, S, nh, H // nh).transpose(1, 2)
+
+
+def _attention(q, k, v, nh, add_mask=None):
+    """softmax(q k^T * d^-0.5 + mask) v  -- HF modeling_vit.py:164-189 / modeling_roberta.py:158-183."""
+    qh, kh, vh = _heads(q, nh), _heads(k, nh), _heads(v, nh)
+    s = torch.matmul(qh, kh.transpose(2, 3)) * (qh.shape[-1] ** -0.5)
+    if add_mask is not None:
+        s = s + add_mask
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, vh)  # [B,nh,S,d]
+    B, _, S, _ = o.shape
+    return o.transpose(1, 2).reshape(B, S, -1)
+
+
+def patch_embed(cfg, sd, pixel_values):
+    """CustomPatchEmbeddings.forward -- src/models/trocr_model.py:79-92 (Conv2d k=s=patch; h-major patches)."""
+    B, C, H, W = pixel_values.shape
+    if H != cfg.image_h or W != cfg.image_w:
+        raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({cfg.image_h}*{cfg.image_w}).")
+    x = F.conv2d(pixel_values, sd["encoder.patch_embeddings.projection.weight"],
+                 sd["encoder.patch_embeddings.projection.bias"], stride=(cfg.patch_h, cfg.patch_w))
+    return x.flatten(2).transpose(1, 2)
+
+
+def encoder_forward(cfg, sd, pixel_values, stages=None):
+    """ViTEncoder.forward -- src/models/trocr_model.py:169-202; layers = HF ViTLayer (modeling_vit.py:257-286)."""
+    B = pixel_values.shape[0]
+    x = patch_embed(cfg, sd, pixel_values)
+    if stages is not None:
+        stages["patch_embed"] = x
+    cls = sd["encoder.cls_token"].expand(B, -1, -1)
+    x = torch.cat((cls, x), dim=1) + sd["encoder.position_embeddings"]   # :183-187 (dropout off)
+    if stages is not None:
+        stages["enc_embed"] = x
+    nh = cfg.enc_heads
+    for i in range(cfg.enc_layers):
+        p = f"encoder.encoder.layer.{i}."
+        h = _ln(x, sd[p + "layernorm_before.weight"], sd[p + "layernorm_before.bias"], cfg.ln_eps)
+        q = F.linear(h, sd[p + "attention.attention.query.weight"], sd[p + "attention.attention.query.bias"])
+        k = F.linear(h, sd[p + "attention.attention.key.weight"], sd[p + "attention.attention.key.bias"])
+        v = F.linear(h, sd[p + "attention.attention.value.weight"], sd[p + "attention.attention.value.bias"])
+        a = _attention(q, k, v, nh)
+        x = x + F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        h = _ln(x, sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"], cfg.ln_eps)
+        h = _gelu(F.linear(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        x = x + F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        if stages is not None:
+            stages[f"enc_layer{i}"] = x
+    x = _ln(x, sd["encoder.layernorm.weight"], sd["encoder.layernorm.bias"], cfg.ln_eps)  # :197
+    x = x[:, 1:, :]                                                                       # :200
+    if stages is not None:
+        stages["enc_out"] = x
+    return x
+
+
+def position_ids(ids, pad_id):
+    """create_position_ids_from_input_ids -- HF modeling_roberta.py:142-155."""
+    m = (ids != pad_id).to(torch.int64)
+    return torch.cumsum(m, dim=1) * m + pad_id
+
+
+def decoder_forward(cfg, sd, input_ids, enc, stages=None):
+    """RobertaForCausalLM(is_decoder, add_cross_attention) teacher-forced forward.
+
+    embeddings: HF modeling_roberta.py:75-122; layer (post-LN): :421-464 with self-attn :186-250,
+    cross-attn :253-326, output blocks :329-340 / :372-398; masks :645-680 (causal AND key != pad,
+    no encoder mask); head :877-893.  Attention mask built from ids as in
+    src/models/trocr_model.py:278.
+    """
+    r = "decoder.roberta."
+    B, T = input_ids.shape
+    pos = position_ids(input_ids, cfg.pad_id)
+    x = (sd[r + "embeddings.word_embeddings.weight"][input_ids]
+         + sd[r + "embeddings.token_type_embeddings.weight"][0]
+         + sd[r + "embeddings.position_embeddings.weight"][pos])
+    x = _ln(x, sd[r + "embeddings.LayerNorm.weight"], sd[r + "embeddings.LayerNorm.bias"], cfg.ln_eps)
+    if stages is not None:
+        stages["dec_embed"] = x
+    neg = torch.finfo(x.dtype).min
+    causal = torch.ones(T, T, dtype=torch.bool).tril()
+    keep = causal[None, None, :, :] & (input_ids != cfg.pad_id)[:, None, None, :]
+    mask = torch.zeros(B, 1, T, T, dtype=x.dtype).masked_fill(~keep, neg)
+    nh = cfg.dec_heads
+    for i in range(cfg.dec_layers):
+        p = r + f"encoder.layer.{i}."
+        q = F.linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"])
+        k = F.linear(x, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"])
+        v = F.linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"])
+        a = _attention(q, k, v, nh, mask)
+        a = F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        x = _ln(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
+        q = F.linear(x, sd[p + "crossattention.self.query.weight"], sd[p + "crossattention.self.query.bias"])
+        k = F.linear(enc, sd[p + "crossattention.self.key.weight"], sd[p + "crossattention.self.key.bias"])
+        v = F.linear(enc, sd[p + "crossattention.self.value.weight"], sd[p + "crossattention.self.value.bias"])
+        a = _attention(q, k, v, nh)
+        a = F.linear(a, sd[p + "crossattention.output.dense.weight"], sd[p + "crossattention.output.dense.bias"])
+        x = _ln(a + x, sd[p + "crossattention.output.LayerNorm.weight"], sd[p + "crossattention.output.LayerNorm.bias"], cfg.ln_eps)
+        h = _gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        h = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        x = _ln(h + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], cfg.ln_eps)
+        if stages is not None:
+            stages[f"dec_layer{i}"] = x
+    h = _gelu(F.linear(x, sd["decoder.lm_head.dense.weight"], sd["decoder.lm_head.dense.bias"]))
+    h = _ln(h, sd["decoder.lm_head.layer_norm.weight"], sd["decoder.lm_head.layer_norm.bias"], cfg.ln_eps)
+    # tied: lm_head.decoder.weight IS word_embeddings.weight (modeling_roberta.py:684-687)
+    return F.linear(h, sd[r + "embeddings.word_embeddings.weight"], sd["decoder.lm_head.bias"])
+
+
+def forward(cfg, sd, pixel_values, labels, stages=None):
+    """TrOCRModel.forward, training branch -- src/models/trocr_model.py:258-297.  Returns (logits, loss)."""
+    enc = encoder_forward(cfg, sd, pixel_values, stages)
+    if cfg.has_proj:
+        enc = F.linear(enc, sd["encoder_decoder_proj.weight"], sd["encoder_decoder_proj.bias"])  # :269
+    if stages is not None:
+        stages["proj_out"] = enc
+    ids = labels[:, :-1].contiguous()       # :274
+    tgt = labels[:, 1:].contiguous()        # :275
+    logits = decoder_forward(cfg, sd, ids, enc, stages)
+    loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), tgt.reshape(-1), ignore_index=cfg.pad_id)  # :256,:292
+    return logits, loss
+
+
+def leaf_state_dict(sd_np, dtype=torch.float32, requires_grad=True):
+    """numpy HF-named dict -> torch leaves; tied aliases dropped (they share storage)."""
+    out = {}
+    for k, v in sd_np.items():
+        if k.startswith("decoder.lm_head.decoder."):
+            continue
+        t = torch.tensor(v, dtype=dtype)
+        t.requires_grad_(requires_grad)
+        out[k] = t
+    return out
+
+
+def forward_backward(cfg, sd_np, pixel_values, labels, dtype=torch.float32, want_stages=False):
+    """One teacher-forced step; returns dict(logits, loss, grads{hf_name: ndarray}, stages)."""
+    sd = leaf_state_dict(sd_np, dtype)
+    stages = {} if want_stages else None
+    logits, loss = forward(cfg, sd, torch.as_tensor(pixel_values).to(dtype), torch.as_tensor(labels), stages)
+    loss.backward()
+    grads = {k: (v.grad.detach().numpy() if v.grad is not None else None) for k, v in sd.items()}
+    return {"logits": logits.detach().numpy(), "loss": float(loss.detach()), "grads": grads,
+            "stages": {k: v.detach().numpy() for k, v in (stages or {}).items()}}
+
+
+# ---- runtime policy restated: clip + optimizer --------------------------------
+def clip_grad_norm(grads, max_norm=1.0):
+    """torch.nn.utils.clip_grad_norm_ as Lightning applies it (scripts/train_trocr.py:175):
+    total L2 norm over all grads; scale = max_norm / (norm + 1e-6), clamped to 1."""
+    total = math.sqrt(sum(float((g.astype("float64") ** 2).sum()) for g in grads))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    return total, coef
+
+
+class RAdamScheduleFreeState:
+    """Host-side scalars of schedulefree.RAdamScheduleFree (parity UNPINNED, see module header).
+
+    Restated from the Schedule-Free paper (Defazio et al. 2024) + the RAdam rectification:
+      y (train-mode params) , z (base iterate), v (second moment);  x = eval-mode params.
+    Reference call site: src/models/trocr_model.py:412-421 (lr 1e-4, betas (0.9,0.999), eps 1e-8, wd 0),
+    mode hooks :423-451.
+    """
+
+    def __init__(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                 r=0.0, weight_lr_power=2.0, silent_sgd_phase=True):
+        self.lr, self.beta1, self.beta2, self.eps, self.wd = lr, beta1, beta2, eps, weight_decay
+        self.r, self.wlp, self.silent = r, weight_lr_power, silent_sgd_phase
+        self.k = 0
+        self.lr_max = -1.0
+        self.weight_sum = 0.0
+
+    def next_scalars(self):
+        """Advance one step; returns (lr_t, ckp1, bias_correction2, use_adaptive)."""
+        step = self.k + 1
+        beta2_t = self.beta2 ** step
+        bc2 = 1.0 - beta2_t
+        rho_inf = 2.0 / (1.0 - self.beta2) - 1.0
+        rho_t = rho_inf - 2.0 * step * beta2_t / bc2
+        if rho_t > 4.0:
+            rect = math.sqrt((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t))
+        else:
+            rect = float(not self.silent)
+        lr = self.lr * rect
+        self.lr_max = max(lr, self.lr_max)
+        weight = (step ** self.r) * (self.lr_max ** self.wlp)
+        self.weight_sum += weight
+        ckp1 = weight / self.weight_sum if self.weight_sum != 0 else 0.0
+        self.k = step
+        return lr, ckp1, bc2, rho_t > 4.0
+
+
+def radam_schedulefree_step(state, y, z, v, g):
+    """In-place numpy/torch update of (y, z, v) given grad g (already clipped)."""
+    lr, ckp1, bc2, adaptive = state.next_scalars()
+    v *= state.beta2
+    v += (1.0 - state.beta2) * g * g
+    if adaptive:
+        gn = g / ((v / bc2) ** 0.5 + state.eps)
+    else:
+        gn = g.copy() if hasattr(g, "copy") else g.clone()
+    if state.wd:
+        gn = gn + state.wd * y
+    y += ckp1 * (z - y)                                  # y.lerp_(z, ckp1)
+    y += lr * (state.beta1 * (1.0 - ckp1) - 1.0) * gn    # y.add_(gn, alpha=adaptive_y_lr)
+    z -= lr * gn
+    return lr, ckp1
+
+
+def to_eval(y, z, beta1):
+    """optimizer.eval(): p <- lerp(p, z, 1 - 1/beta1)   (y -> x)."""
+    return y + (1.0 - 1.0 / beta1) * (z - y)
+
+
+def to_train(x, z, beta1):
+    """optimizer.train(): p <- lerp(p, z, 1 - beta1)    (x -> y)."""
+    return x + (1.0 - beta1) * (z - x)
+
+
+# ---- CER: src/models/trocr_model.py:400-410 (editdistance.eval == Levenshtein) ---
+def levenshtein(a, b) -> int:
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def calculate_cer(pred_text: str, target_text: str) -> float:
+    if len(target_text) == 0:
+        return 1.0 if len(pred_text) > 0 else 0.0
+    return levenshtein(pred_text, target_text) / len(target_text)
