@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: TrOCR line-OCR TRAINING step (forward + CE + hand-written backward + gradient
+all-reduce + clip 1.0 + RAdamScheduleFree + bf16 weight refresh), synthetic 64x640 crops, dropout ON.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  value = line-images/s of the whole job (all ranks), inputs resident in HBM.
+roofline: the bf16 MFMA GEMM family gemm_nt_kernel<*> (every nn.Linear forward and input-gradient), timed live
+with HIP events around each of its launches inside the timed region (kzv_prof_*), priced by its algorithmic
+2*M*N*K FLOPs against the 2.5 PFLOP/s dense bf16 peak of /opt/skills/guides/MI355X_MICROARCH.md.
+cpu_baseline: oracle/trocr_oracle.py (a port, not the reference) timed on this box's host cores, rank 0, N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import dataclasses
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "kuzushiji-vision_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def train_flops_per_image(cfg, T):
+    """ALGORITHMIC FLOPs per image (SURVEY.md section 8(d) formulae): 2*MACs, full S^2 attention, train = 3 x fwd."""
+    S, H, F = cfg.enc_seq, cfg.enc_hidden, cfg.enc_ffn
+    enc_layer = 2 * S * H * H * 3 + 2 * S * S * H * 2 + 2 * S * H * H + 2 * S * H * F * 2
+    patch = 2 * cfg.num_patches * cfg.patch_dim * H
+    proj = 2 * cfg.num_patches * H * cfg.dec_hidden if cfg.has_proj else 0
+    Hd, Fd, Sk = cfg.dec_hidden, cfg.dec_ffn, cfg.num_patches
+    dec_layer = (2 * T * Hd * Hd * 3 + 2 * T * T * Hd * 2 + 2 * T * Hd * Hd
+                 + 2 * T * Hd * Hd + 2 * Sk * Hd * Hd * 2 + 2 * T * Sk * Hd * 2 + 2 * T * Hd * Hd
+                 + 2 * T * Hd * Fd * 2)
+    head = 2 * T * Hd * Hd + 2 * T * Hd * cfg.vocab
+    fwd = patch + cfg.enc_layers * enc_layer + proj + cfg.dec_layers * dec_layer + head
+    return 3.0 * fwd
+
+
+def cpu_baseline(cfg, label_len, sample_batch, steps):
+    """Oracle (CPU port) train step: fwd + CE + autograd bwd + clip + RAdamScheduleFree, fp32, all host cores."""
+    import numpy as np
+    import torch
+    from kzv import params as P
+    from kzv.data import synthetic_batch
+    from oracle import trocr_oracle as O
+    sd = O.leaf_state_dict(P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 42)))
+    px, lab = synthetic_batch(cfg, sample_batch, label_len, seed=1)
+    px_t, lab_t = torch.from_numpy(px), torch.from_numpy(lab)
+    st = O.RAdamScheduleFreeState()
+    z = {k: v.detach().clone() for k, v in sd.items()}
+    vv = {k: torch.zeros_like(v) for k, v in sd.items()}
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        for v in sd.values():
+            v.grad = None
+        _, loss = O.forward(cfg, sd, px_t, lab_t)
+        loss.backward()
+        grads = [v.grad for v in sd.values()]
+        total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
+        coef = min(1.0, 1.0 / (total + 1e-6))
+        lr, ckp1, bc2, adaptive = st.next_scalars()
+        with torch.no_grad():
+            for k, p_ in sd.items():
+                g = p_.grad * coef
+                vv[k].mul_(st.beta2).addcmul_(g, g, value=1 - st.beta2)
+                gn = g / ((vv[k] / bc2).sqrt() + st.eps) if adaptive else g
+                p_.lerp_(z[k], ckp1)
+                p_.add_(gn, alpha=lr * (st.beta1 * (1 - ckp1) - 1))
+                z[k].sub_(gn, alpha=lr)
+        if it > 0:   # first iteration = warm-up
+            times.append(time.perf_counter() - t0)
+    dt = float(np.mean(times))
+    return {"value": sample_batch / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps (after 1 warm-up) of batch {sample_batch} on the same geometry, fp32, "
+                      f"dropout off, oracle/trocr_oracle.py with torch CPU autograd; {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling: global = batch * gpus)")
+    ap.add_argument("--dec-layers", type=int, default=6, help="6 = BASELINE.json configs[1]; 12 = reference decoder")
+    ap.add_argument("--label-len", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    from kzv import _lib as L
+    from kzv.config import vit_b_config
+    from kzv.data import build_decoder_dir, synthetic_batch
+    from kzv.model import TrOCRModel
+    from kzv.trainer import Stepper, init_distributed
+
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    cfg = vit_b_config(dec_layers=args.dec_layers)
+    lib = L.load()
+
+    with tempfile.TemporaryDirectory() as tmp:
+        d = build_decoder_dir(os.path.join(tmp, "dec"), cfg)
+        model = TrOCRModel(cfg.encoder_config_dict(), d, device=dev, init_seed=42, load_tokenizer=False)
+    model._step_seed = 1_000_003 * rank            # per-rank dropout streams
+    opt = model.configure_optimizers()
+    model.train()
+    stepper = Stepper(model, opt, world=world, max_grad_norm=1.0)
+    px, lab = synthetic_batch(cfg, args.batch, args.label_len, seed=1 + rank)
+    batch = {"pixel_values": torch.from_numpy(px).to(dev), "labels": torch.from_numpy(lab).to(dev)}   # resident in HBM
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        stepper.step(batch, i)
+    barrier()
+    L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = stepper.step(batch, i)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.check(lib.kzv_prof_enable(0, 0), "prof_disable")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    def collect(kind):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        L.check(lib.kzv_prof_collect(kind, C.byref(ms), C.byref(fl), C.byref(n)), "prof_collect")
+        return ms.value, fl.value, n.value
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        T = args.label_len - 1
+        ms, fl, n = collect(0)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        step_flops = train_flops_per_image(cfg, T) * args.batch
+        others = {}
+        for kind, name in ((1, "gemm_tn_kernel"), (2, "attn_fwd_kernel"), (3, "attn_bwd_kernel")):
+            m2, f2, n2 = collect(kind)
+            others[name] = {"ms_per_step": m2 / args.steps, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0,
+                            "launches_per_step": n2 / args.steps}
+        out = {
+            "metric": "line-images/sec (train)", "value": imgs / dt, "unit": "img/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"TrOCR train step: ViT-B/16 (12L/768/12h/3072) on 64x640 crops (S_e=161) + RoBERTa "
+                                   f"decoder {args.dec_layers}L/256/4h/768, V=4300 one-char vocab, labels [B,{args.label_len}], "
+                                   f"dropout 0.1, clip 1.0, RAdamScheduleFree; BASELINE.json configs[{1 if world == 1 else 2}]",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "final_loss": final_loss},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> (bf16 MFMA 16x16x32, all nn.Linear fwd + dgrad)",
+                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                         "traffic": None, "launches_per_step": n / args.steps, "avg_launch_us": (ms / n * 1e3) if n else None,
+                         "kernel_ms_per_step": ms / args.steps,
+                         "whole_step_TFLOP/s": step_flops / (dt / args.steps) / 1e12,
+                         "whole_step_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
+                         "other_kernels": others},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.label_len, args.cpu_sample_batch, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/* libkzv -- C ABI of the MI355X-native TrOCR line-OCR training engine.
+ *
+ * The reference (Kotomiya07/kuzushiji-vision) has no FFI for this path: every FLOP runs inside
+ * PyTorch / HF transformers behind the Python class `TrOCRModel`
+ * (src/models/trocr_model.py:205-460).  This header is the boundary a maintainer would bind from
+ * that class (ctypes stub: INTEGRATION.md).  Each entry point names the reference call it replaces.
+ *
+ * Conventions: every function returns 0 on success, a negative KZV_E_* code on error and records
+ * a message readable through kzv_last_error().  All pointers named d_* are DEVICE pointers owned
+ * by the caller (torch tensors in the Python host); the library never allocates device memory and
+ * keeps no global state besides the last-error string and one 4 KiB device page of zeros (allocated on
+ * first use; LDS-DMA loads of out-of-range tile rows are pointed at it).  `stream` is a hipStream_t passed as void*.
+ * One model handle per process/GPU; a handle is not re-entrant.
+ */
+#ifndef KZV_H
+#define KZV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZV_OK 0
+#define KZV_E_ARG (-1)     /* bad argument / shape (reference: ValueError, trocr_model.py:83-86) */
+#define KZV_E_HIP (-2)     /* HIP runtime error */
+#define KZV_E_STATE (-3)   /* call order violated (e.g. backward before forward) */
+
+const char* kzv_last_error(void);
+int kzv_version(void);
+
+/* ------------------------------------------------------------------ geometry */
+/* Mirrors encoder_config (trocr_model.py:234-244) + the decoder's RobertaConfig
+ * (train_language_model_scratch.py:406-428). */
+typedef struct kzv_config {
+    int32_t image_h, image_w, patch_h, patch_w, channels;
+    int32_t enc_hidden, enc_layers, enc_heads, enc_ffn;
+    int32_t dec_hidden, dec_layers, dec_heads, dec_ffn;
+    int32_t vocab, max_pos, type_vocab, pad_id;
+    float enc_hidden_dropout, enc_attn_dropout, dec_hidden_dropout, dec_attn_dropout;
+    float ln_eps;
+} kzv_config;
+
+typedef struct kzv_model kzv_model;
+
+/* TrOCRModel.__init__ (trocr_model.py:208-256): validates geometry, builds the parameter table. */
+int kzv_model_create(const kzv_config* cfg, kzv_model** out);
+int kzv_model_destroy(kzv_model* m);
+
+/* Parameter table = the reference's state_dict, fused/flattened (kzv/params.py documents the
+ * mapping to HF names).  Offsets are in fp32 ELEMENTS into the flat master buffer. */
+int kzv_param_count(const kzv_model* m);
+int kzv_param_info(const kzv_model* m, int i, const char** name, int64_t* offset, int64_t* rows, int64_t* cols);
+int64_t kzv_param_total(const kzv_model* m);                 /* padded element count of the flat buffer */
+
+/* Bytes of caller-provided device memory needed for a per-GPU batch of B crops with labels [B, L]. */
+int64_t kzv_workspace_bytes(const kzv_model* m, int batch, int label_len);
+
+/* Bind caller-owned device buffers: fp32 master params, fp32 grads (same layout), workspace.
+ * (the reference's nn.Parameter storage + autograd .grad + activation memory) */
+int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, void* d_workspace, int64_t workspace_bytes,
+                   int batch, int label_len);
+
+/* Refresh the bf16 compute copies (W and W^T) from the fp32 masters; call after the masters change
+ * (load_state_dict / optimizer step).  Stands in for autocast's per-op weight cast. */
+int kzv_model_sync_weights(kzv_model* m, void* stream);
+
+/* TrOCRModel.forward(pixel_values, labels) training branch (trocr_model.py:258-297).
+ *   d_pixel_values fp32 [B,C,H,W]; d_labels int64 [B,L]; d_loss fp32[1] (mean CE over non-pad targets);
+ *   d_logits fp32 [B,L-1,V] or NULL.  train!=0 applies dropout (keyed by `seed`) and keeps what
+ *   backward needs.  Image-size mismatch is the caller's ValueError (host checks shapes). */
+int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels,
+                     float* d_loss, float* d_logits, int train, uint64_t seed, void* stream);
+
+/* loss.backward() for the step above: fills the bound fp32 grad buffer (which must be zero on entry;
+ * kzv_zero_grads does that).  Backward is split in `kzv_backward_segments()` segments so the host can
+ * launch an RCCL all-reduce for a segment's finished gradients while later segments still run
+ * (Lightning DDP bucket overlap, scripts/train_trocr.py:166-169).  After segment s returns (work
+ * enqueued on `stream`), grads in [lo, hi) of kzv_backward_segment_range(s) are final. */
+int kzv_zero_grads(kzv_model* m, void* stream);
+int kzv_backward_segments(const kzv_model* m);
+int kzv_backward_segment(kzv_model* m, int seg, void* stream);
+int kzv_backward_segment_range(const kzv_model* m, int seg, int64_t* lo, int64_t* hi);
+int kzv_backward(kzv_model* m, void* stream);               /* all segments */
+
+/* gradient_clip_val (scripts/train_trocr.py:175) + RAdamScheduleFree.step (trocr_model.py:412-421),
+ * fused over the flat buffers.  d_z, d_v: optimizer state (z iterate, second moment), same layout.
+ * d_scratch: >= 4 KiB fp32 scratch (partial norms).  Host supplies the step scalars (kzv/optim.py). */
+typedef struct kzv_opt_step {
+    float lr_t;          /* lr * RAdam rectification for this step (0 in the silent phase) */
+    float ckp1;          /* schedule-free averaging weight c_{k+1} */
+    float beta1, beta2, eps, weight_decay;
+    float bias_correction2;
+    int32_t adaptive;    /* 1 once rho_t > 4 (use v), else plain (silent) step */
+    float max_grad_norm; /* <= 0 disables clipping */
+    float grad_scale;    /* multiplied into grads before everything (1/world for DDP mean) */
+} kzv_opt_step;
+int kzv_grad_sqnorm(const float* d_grads, int64_t n, float* d_out1, float* d_scratch, void* stream);
+int kzv_clip_and_step(float* d_params, float* d_z, float* d_v, const float* d_grads, int64_t n,
+                      const float* d_sqnorm, const kzv_opt_step* s, void* stream);
+/* optimizer.eval()/train() parameter swap (trocr_model.py:423-451): p <- p + w*(z - p) */
+int kzv_lerp_params(float* d_params, const float* d_z, int64_t n, float w, void* stream);
+
+/* -------------------------------------------------------- per-op entry points (unit parity tests) */
+enum { KZV_EPI_BF16 = 0, KZV_EPI_F32 = 1, KZV_EPI_GELU = 2, KZV_EPI_RESID = 3, KZV_EPI_DGELU = 4,
+       KZV_EPI_GELU_F32 = 5 /* like GELU but C is fp32 (feeds a LayerNorm) */ };
+
+/* C[M,N] = A[M,K] . B[N,K]^T (+bias) with a fused epilogue; bf16 operands, fp32 accumulate (MFMA).
+ * Replaces every nn.Linear forward / input-gradient on the path. */
+typedef struct kzv_gemm_nt_args {
+    const void* A; int64_t lda;       /* bf16 [M,K] */
+    const void* B; int64_t ldb;       /* bf16 [n_valid,K] */
+    void* C; int64_t ldc;             /* bf16 or fp32 [M,N] by epilogue */
+    const float* bias;                /* fp32 [n_valid] or NULL */
+    const float* resid; int64_t ldr;  /* KZV_EPI_RESID: fp32 [M,N] */
+    void* aux; int64_t ldaux;         /* GELU: bf16 pre-activation OUT; DGELU: bf16 pre-activation IN */
+    int32_t M, N, K, n_valid;         /* N = columns stored (mult of 4), rows of B >= n_valid read as 0 */
+    float drop_p; uint32_t drop_key;  /* KZV_EPI_RESID dropout on (acc+bias); p=0 -> off */
+} kzv_gemm_nt_args;
+int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream);
+
+/* OUT[N,K] (+)= P[Mtok,N]^T . Q[Mtok,K]   (weight gradient; fp32 atomics over token splits) */
+typedef struct kzv_gemm_tn_args {
+    const void* P; int64_t ldp;       /* bf16 [Mtok, N] */
+    const void* Q; int64_t ldq;       /* bf16 [Mtok, K] */
+    float* OUT; int64_t ldo;          /* fp32 [n_store, K] accumulated into */
+    int32_t Mtok, N, K, n_store;
+} kzv_gemm_tn_args;
+int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream);
+
+/* LayerNorm over the last dim (fp32 statistics, eps inside rsqrt).  x fp32 [rows, H].
+ * Replaces nn.LayerNorm in ViTLayer / RobertaLayer / heads. */
+int kzv_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                      float* stats /* [rows,2] mean,rstd */, int rows, int H, float eps, void* stream);
+/* dx(+)= LN backward; dy bf16 or fp32; dgamma/dbeta accumulated (atomics). */
+int kzv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma,
+                      float* dx, int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, void* stream);
+
+/* Multi-head attention, head_dim 64, one workgroup per (batch, head).
+ * mode 0: no mask (ViT self-attn / decoder cross-attn); mode 1: causal AND key-not-pad (decoder self). */
+typedef struct kzv_attn_args {
+    const void* Q; const void* K; const void* V;   /* bf16, row strides ldq/ldk/ldv, head h at col h*64 */
+    void* O;                                        /* bf16 [B*Sq, ldo] */
+    float* LSE;                                     /* fp32 [B, heads, Sq] */
+    const void* dO; void* dQ; void* dK; void* dV;   /* backward only (same strides as O/Q/K/V) */
+    int64_t ldq, ldk, ldv, ldo;
+    const int64_t* ids; int64_t ld_ids; int32_t pad_id;   /* mode 1: decoder input ids [B, ld_ids] */
+    int32_t B, heads, Sq, Sk, mode;
+    float drop_p; uint32_t drop_key;
+} kzv_attn_args;
+int kzv_attn_fwd(const kzv_attn_args* a, void* stream);
+int kzv_attn_bwd(const kzv_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------- measurement hooks (bench.py roofline leg)
+ * When enabled, every launch of the hot kernels is bracketed by HIP events on its own stream.
+ * kind: 0 gemm_nt, 1 gemm_tn, 2 attn_fwd, 3 attn_bwd.  work = algorithmic FLOPs (2*M*N*K; 4*B*h*Sq*Sk*64 /
+ * 10*B*h*Sq*Sk*64 for attention fwd / bwd).  Collect after synchronising the stream. */
+int kzv_prof_enable(int on, int capacity);
+int kzv_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches);
+uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZV_H */

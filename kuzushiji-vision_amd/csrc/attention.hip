@@ -1,0 +1,356 @@
+// Multi-head attention forward / backward for short sequences (Sq, Sk <= 192), head_dim 64, bf16 MFMA.
+//
+// Replaces eager_attention_forward in HF ViT (modeling_vit.py:164-189: fp32 softmax, prob dropout) and the
+// RoBERTa self/cross attention (modeling_roberta.py:158-183, 186-326) with masks from :645-680 built as
+// src/models/trocr_model.py:278 does (causal AND key != pad; cross attention unmasked).
+//
+// One 256-thread workgroup per (batch, head): the head's whole K and V (<= 192 x 64 bf16 = 24 KiB each)
+// are staged once into LDS by LDS-DMA (XOR-swizzled 128-B rows), so HBM traffic is the algorithmic
+// minimum (Q, K, V read once, O written once).
+//
+// forward : each wave owns 16-query tiles.  S^T = K.Q^T is computed with the KEY on the accumulator
+//           rows, so a query's scores live in one lane column: softmax = register max/sum + 2 shuffles,
+//           and the P^T accumulators are directly the B operand of O^T = V^T.P^T (no LDS round trip);
+//           V^T fragments come from the row-major V image through ds_read_b64_tr_b16.
+// backward: flash-style recompute from the saved log-sum-exp.  Each wave owns key tiles and keeps
+//           dK^T, dV^T for them in registers across the query sweep (no cross-workgroup reduction);
+//           S and dP are computed with the key on the lane so their accumulators are the B operands of
+//           dV^T += dO^T.P and dK^T += Q^T.dS; only dS crosses LDS (bf16, 32-query slab) for dQ.
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+
+namespace {
+
+constexpr int KT = 12;            // key tiles of 16 -> Sk <= 192
+constexpr int SP = KT * 16;       // padded rows of every LDS image
+constexpr int IMG = SP * 128;     // bytes of one [SP][64] bf16 image
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnP {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O; float* LSE;
+    const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+    const void* zero16;
+    int64_t ldq, ldk, ldv, ldo;
+    const int64_t* ids; int64_t ld_ids; int pad_id;
+    int B, heads, Sq, Sk;
+    float scale; unsigned thr16; float inv_keep; unsigned key;
+};
+
+// stage `nvalid` rows (64 bf16 each, row stride ld) into a swizzled [SP][64] LDS image; rows >= nvalid are zero
+__device__ __forceinline__ void stage_image(char* img, const bf16_t* src, int64_t ld, int nvalid, const void* zero16,
+                                            int w, int lane) {
+    const int r8 = lane >> 3;
+    for (int pc = w; pc < SP / 8; pc += 4) {
+        const int row = pc * 8 + r8;
+        const int chunk = (lane & 7) ^ (row & 7);
+        const void* s = row < nvalid ? (const void*)(src + (int64_t)row * ld + chunk * 8) : zero16;
+        glds16(s, img + pc * 1024);
+    }
+}
+__device__ __forceinline__ bf16x8 frag_row(const char* img, int row, int chunk) {
+    return *(const bf16x8*)(img + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+// transposing read: block rows rb..rb+3 (supplied by lane groups of 4), 16 columns starting at chunk c2 (2 chunks)
+__device__ __forceinline__ bf16x4 frag_tr(const char* img, int rb, int c2, int l15) {
+    const int row = rb + (l15 >> 2);
+    const int chunk = c2 + ((l15 >> 1) & 1);
+    return lds_tr16(img + row * 128 + ((chunk ^ (row & 7)) << 4) + (l15 & 1) * 8);
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
+    const unsigned u0 = pack_bf2(a[0], a[1]), u1 = pack_bf2(a[2], a[3]), u2 = pack_bf2(b[0], b[1]), u3 = pack_bf2(b[2], b[3]);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    return __builtin_bit_cast(bf16x8, (u32x4){u0, u1, u2, u3});
+}
+__device__ __forceinline__ float keep_of(const AttnP& p, unsigned e) {
+    const unsigned bits = drop_bits(p.key, e >> 1);
+    return drop_keep(bits, e & 1, p.thr16, p.inv_keep);
+}
+
+// ================================================================================================ forward
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem; char* Vs = smem + IMG;
+    int* kvalid = (int*)(smem + 2 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
+    const bf16_t* Kb = p.K + (int64_t)b * p.Sk * p.ldk + h * 64;
+    const bf16_t* Vb = p.V + (int64_t)b * p.Sk * p.ldv + h * 64;
+    stage_image(Ks, Kb, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image(Vs, Vb, p.ldv, p.Sk, p.zero16, w, lane);
+    if (tid < SP) kvalid[tid] = tid < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + tid] != p.pad_id);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nkt = (p.Sk + 15) >> 4, nqt = (p.Sq + 15) >> 4;
+    const float sc = p.scale * LOG2E;
+    for (int qt = w; qt < nqt; qt += 4) {
+        const int q = qt * 16 + l15;
+        const int qc = min(q, p.Sq - 1);
+        const bf16_t* qrow = p.Q + ((int64_t)b * p.Sq + qc) * p.ldq + h * 64 + 8 * g;
+        const bf16x8 q0 = *(const bf16x8*)qrow, q1 = *(const bf16x8*)(qrow + 32);
+        const int nk = MODE == 1 ? min(nkt, qt + 1) : nkt;   // causal: key tiles above the diagonal are empty
+        f32x4 s[KT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kt < nk) {
+                const int krow = kt * 16 + l15;
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, krow, g), q0, s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, krow, 4 + g), q1, s[kt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    const bool ok = kvalid[key] && (MODE == 0 || key <= q);
+                    s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const bool dead = mx == -INFINITY;                    // fully masked row -> zeros, LSE = +inf
+        const float mref = dead ? 0.f : mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            if (kt < nk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mref); sum += s[kt][r]; }
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = dead ? 0.f : 1.f / sum;
+        if (p.LSE && g == 0 && q < p.Sq)
+            p.LSE[((int64_t)b * p.heads + h) * p.Sq + q] = dead ? INFINITY : (mx + log2f(sum)) * (1.f / LOG2E);
+        const unsigned ebase = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)p.Sk;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            if (kt < nk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][r] * inv;
+                    if (p.thr16) v *= keep_of(p, ebase + kt * 16 + 4 * g + r);
+                    s[kt][r] = v;
+                }
+            }
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < KT / 2; ++kp) {
+            if (2 * kp < nk) {
+                const bf16x8 pf = pack8((const float*)&s[2 * kp], (const float*)&s[2 * kp + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const bf16x8 vf = cat8(frag_tr(Vs, kp * 32 + 4 * g, dt * 2, l15), frag_tr(Vs, kp * 32 + 16 + 4 * g, dt * 2, l15));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q < p.Sq) {
+            bf16_t* orow = p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *(uint2*)(orow + dt * 16) = make_uint2(pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3]));
+        }
+    }
+}
+
+// =============================================================================================== backward
+constexpr int DS_STRIDE = SP * 2 + 16;          // bytes per dS row (pad keeps 16-B reads conflict-light)
+constexpr int DS_BYTES = 32 * DS_STRIDE;
+constexpr int BWD_LDS = 4 * IMG + 2 * DS_BYTES + 3 * SP * 4;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem; char* Os = smem + IMG; char* Ks = smem + 2 * IMG; char* Vs = smem + 3 * IMG;
+    char* dSb = smem + 4 * IMG;
+    float* lse = (float*)(dSb + 2 * DS_BYTES);
+    float* dlt = lse + SP;
+    int* kvalid = (int*)(dlt + SP);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
+    const bf16_t* Qb = p.Q + (int64_t)b * p.Sq * p.ldq + h * 64;
+    const bf16_t* dOb = p.dO + (int64_t)b * p.Sq * p.ldo + h * 64;
+    stage_image(Qs, Qb, p.ldq, p.Sq, p.zero16, w, lane);
+    stage_image(Os, dOb, p.ldo, p.Sq, p.zero16, w, lane);
+    stage_image(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    if (tid < SP) {
+        kvalid[tid] = tid < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + tid] != p.pad_id);
+        float l = INFINITY, d = 0.f;
+        if (tid < p.Sq) {
+            l = p.LSE[((int64_t)b * p.heads + h) * p.Sq + tid];
+            const bf16_t* orow = p.O + ((int64_t)b * p.Sq + tid) * p.ldo + h * 64;
+            const bf16_t* drow = dOb + (int64_t)tid * p.ldo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 a = *(const bf16x8*)(orow + c * 8), e = *(const bf16x8*)(drow + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)a[j]) * bf2f((bf16_t)e[j]);
+            }
+        }
+        lse[tid] = l * LOG2E; dlt[tid] = d;
+    }
+    for (int i = tid; i < 2 * DS_BYTES / 16; i += 256) ((uint4*)dSb)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nkt = (p.Sk + 15) >> 4, nqb = (p.Sq + 31) >> 5;
+    const float sc = p.scale * LOG2E;
+    f32x4 dk[3][4], dv[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { dk[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int qb = 0; qb < nqb; ++qb) {
+        char* dS = dSb + (qb & 1) * DS_BYTES;
+        // ---------------- phase A: per owned key tile, S / dP / P / dS for 32 queries; dV^T, dK^T ----------
+        // A operands shared by all key tiles of this wave: dO^T and Q^T fragments over the 32 queries
+        bf16x8 dOt[4], Qt[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dOt[dt] = cat8(frag_tr(Os, qb * 32 + 4 * g, dt * 2, l15), frag_tr(Os, qb * 32 + 16 + 4 * g, dt * 2, l15));
+            Qt[dt] = cat8(frag_tr(Qs, qb * 32 + 4 * g, dt * 2, l15), frag_tr(Qs, qb * 32 + 16 + 4 * g, dt * 2, l15));
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int kt = w + 4 * a;
+            if (kt >= nkt) continue;
+            if (MODE == 1 && kt * 16 > qb * 32 + 31) {   // key tile entirely above the diagonal: dS = 0
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    *(bf16_t*)(dS + ((r >> 2) * 16 + 4 * g + (r & 3)) * DS_STRIDE + (kt * 16 + l15) * 2) = 0;
+                continue;
+            }
+            const int key = kt * 16 + l15;
+            const bf16x8 k0 = frag_row(Ks, key, g), k1 = frag_row(Ks, key, 4 + g);
+            const bf16x8 v0 = frag_row(Vs, key, g), v1 = frag_row(Vs, key, 4 + g);
+            const bool kok = kvalid[key];
+            float pd[8], ds[8];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int qrow = qb * 32 + t2 * 16 + l15;
+                f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, g), k0, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, 4 + g), k1, S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, g), v0, dP, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, 4 + g), v1, dP, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qb * 32 + t2 * 16 + 4 * g + r;
+                    const bool ok = kok && (MODE == 0 || key <= q);
+                    float pr = ok ? exp2f(S[r] * sc - lse[q]) : 0.f;      // lse = +inf for q >= Sq / dead rows
+                    float kp = 1.f;
+                    if (p.thr16) kp = keep_of(p, (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)p.Sk + key);
+                    pd[t2 * 4 + r] = pr * kp;
+                    ds[t2 * 4 + r] = pr * (dP[r] * kp - dlt[q]);
+                    *(bf16_t*)(dS + (t2 * 16 + 4 * g + r) * DS_STRIDE + key * 2) = f2bf(ds[t2 * 4 + r]);
+                }
+            }
+            const bf16x8 pf = pack8(pd, pd + 4), df = pack8(ds, ds + 4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOt[dt], pf, dv[a][dt], 0, 0, 0);
+                dk[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt[dt], df, dk[a][dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // ---------------- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for this 32-query slab ----
+        {
+            const int t2 = w >> 1;
+            const int qloc = t2 * 16 + l15;
+            const int q = qb * 32 + qloc;
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            const int nks = (nkt + 1) >> 1;
+            for (int ks = 0; ks < nks; ++ks) {
+                const bf16x8 dsf = *(const bf16x8*)(dS + qloc * DS_STRIDE + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int dt = (w & 1) * 2 + u;
+                    const bf16x8 kf = cat8(frag_tr(Ks, ks * 32 + 8 * g, dt * 2, l15), frag_tr(Ks, ks * 32 + 8 * g + 4, dt * 2, l15));
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[u], 0, 0, 0);
+                }
+            }
+            if (q < p.Sq) {
+                bf16_t* row = p.dQ + ((int64_t)b * p.Sq + q) * p.ldq + h * 64 + 4 * g;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int dt = (w & 1) * 2 + u;
+                    *(uint2*)(row + dt * 16) = make_uint2(pack_bf2(acc[u][0] * p.scale, acc[u][1] * p.scale),
+                                                          pack_bf2(acc[u][2] * p.scale, acc[u][3] * p.scale));
+                }
+            }
+        }
+        // no barrier here: the next slab writes the OTHER dS buffer; the barrier after its phase A orders
+        // this slab's phase-B reads before the slab after next overwrites this buffer.
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int key = (w + 4 * a) * 16 + l15;
+        if (w + 4 * a >= nkt || key >= p.Sk) continue;
+        bf16_t* krow = p.dK + ((int64_t)b * p.Sk + key) * p.ldk + h * 64 + 4 * g;
+        bf16_t* vrow = p.dV + ((int64_t)b * p.Sk + key) * p.ldv + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *(uint2*)(krow + dt * 16) = make_uint2(pack_bf2(dk[a][dt][0] * p.scale, dk[a][dt][1] * p.scale),
+                                                   pack_bf2(dk[a][dt][2] * p.scale, dk[a][dt][3] * p.scale));
+            *(uint2*)(vrow + dt * 16) = make_uint2(pack_bf2(dv[a][dt][0], dv[a][dt][1]), pack_bf2(dv[a][dt][2], dv[a][dt][3]));
+        }
+    }
+}
+
+int fill(AttnP& p, const kzv_attn_args* a, bool bwd) {
+    if (!a || !a->Q || !a->K || !a->V || !a->O) return kzv_fail(KZV_E_ARG, "attn: null operand");
+    if (a->Sq <= 0 || a->Sk <= 0 || a->Sq > SP || a->Sk > SP) return kzv_fail(KZV_E_ARG, "attn: Sq/Sk must be in 1..%d", SP);
+    if (a->mode == 1 && (!a->ids || a->Sq != a->Sk)) return kzv_fail(KZV_E_ARG, "attn: causal mode needs ids and Sq == Sk");
+    if (a->mode != 0 && a->mode != 1) return kzv_fail(KZV_E_ARG, "attn: unknown mode");
+    if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8) return kzv_fail(KZV_E_ARG, "attn: row strides must be multiples of 8");
+    if (bwd && (!a->dO || !a->dQ || !a->dK || !a->dV || !a->LSE)) return kzv_fail(KZV_E_ARG, "attn_bwd: null gradient operand");
+    p.Q = (const bf16_t*)a->Q; p.K = (const bf16_t*)a->K; p.V = (const bf16_t*)a->V; p.O = (bf16_t*)a->O; p.LSE = a->LSE;
+    p.dO = (const bf16_t*)a->dO; p.dQ = (bf16_t*)a->dQ; p.dK = (bf16_t*)a->dK; p.dV = (bf16_t*)a->dV;
+    p.zero16 = kzv_zero_page();
+    if (!p.zero16) return kzv_fail(KZV_E_HIP, "attn: zero page unavailable");
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+    p.ids = a->ids; p.ld_ids = a->ld_ids; p.pad_id = a->pad_id;
+    p.B = a->B; p.heads = a->heads; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.scale = 0.125f;   // head_dim^-0.5, head_dim = 64
+    kzv_drop_params(a->drop_p, &p.thr16, &p.inv_keep);
+    p.key = a->drop_key;
+    return KZV_OK;
+}
+
+}  // namespace
+
+extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
+    AttnP p;
+    if (int rc = fill(p, a, false)) return rc;
+    const int lds = 2 * IMG + SP * 4;
+    hipStream_t s = (hipStream_t)stream;
+    KzvProfScope prof(2, 4.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
+    if (a->mode == 0) hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(a->B * a->heads), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(a->B * a->heads), dim3(256), lds, s, p);
+    return kzv_check_launch("attn_fwd");
+}
+
+extern "C" int kzv_attn_bwd(const kzv_attn_args* a, void* stream) {
+    AttnP p;
+    if (int rc = fill(p, a, true)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+        attr = true;
+    }
+    KzvProfScope prof(3, 10.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
+    if (a->mode == 0) hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(a->B * a->heads), dim3(256), BWD_LDS, s, p);
+    else hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(a->B * a->heads), dim3(256), BWD_LDS, s, p);
+    return kzv_check_launch("attn_bwd");
+}

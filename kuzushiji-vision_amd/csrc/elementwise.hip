@@ -1,0 +1,365 @@
+// HBM-bound glue kernels of the TrOCR training path (all vectorised 8/16 B per lane).
+//   im2row            -- the data movement half of nn.Conv2d(k=s=patch) (src/models/trocr_model.py:77,89-90)
+//   embed_assemble    -- cat(cls, patches) + position_embeddings, dropout (trocr_model.py:183-190) (+ backward)
+//   cast_drop_colsum  -- backward of "dropout(linear(x))": masked bf16 copy of the upstream grad + bias grad
+//   colsum_bf16       -- bias gradient of a bf16 gradient matrix
+//   dec_prepare / embed_gather / embed_scatter_bwd -- RobertaEmbeddings (HF modeling_roberta.py:75-155)
+//   ce_fwd_bwd        -- nn.CrossEntropyLoss(ignore_index=pad) forward + dlogits (trocr_model.py:256,292)
+//   cast_weights      -- fp32 master -> bf16 W and W^T compute copies (autocast's weight cast)
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "kzv_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ im2row
+// out[(b*np + gy*gw + gx)][c*ph*pw + i*pw + j] = px[b][c][gy*ph + i][gx*pw + j]; one thread = 8 j's.
+__global__ void im2row_kernel(const float* __restrict__ px, bf16_t* __restrict__ out, int B, int C, int H, int W,
+                              int ph, int pw, int64_t total8) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total8) return;
+    const int gw = W / pw, gh = H / ph, pw8 = pw / 8;
+    const int kdim = C * ph * pw;
+    int64_t r = t;
+    const int j8 = r % pw8; r /= pw8;
+    const int i = r % ph; r /= ph;
+    const int c = r % C; r /= C;
+    const int gx = r % gw; r /= gw;
+    const int gy = r % gh; r /= gh;
+    const int b = (int)r;
+    const float* src = px + (((int64_t)b * C + c) * H + gy * ph + i) * W + gx * pw + j8 * 8;
+    const float4 a = ((const float4*)src)[0], d = ((const float4*)src)[1];
+    bf16_t* dst = out + ((int64_t)b * gh * gw + gy * gw + gx) * kdim + (c * ph + i) * pw + j8 * 8;
+    *(uint4*)dst = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
+}
+
+// -------------------------------------------------------------------------------- embed assemble (+bwd)
+__global__ void embed_assemble_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                      const float* __restrict__ pos, float* __restrict__ x0, int B, int np, int He,
+                                      unsigned thr16, float inv_keep, unsigned key) {
+    const int S = np + 1, h4 = He / 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * S * h4) return;
+    const int c = t % h4;
+    const int64_t row = t / h4;
+    const int s = row % S, b = (int)(row / S);
+    const float4 a = s == 0 ? ((const float4*)cls)[c] : ((const float4*)(pe + ((int64_t)b * np + s - 1) * He))[c];
+    const float4 p = ((const float4*)(pos + (int64_t)s * He))[c];
+    float o0 = a.x + p.x, o1 = a.y + p.y, o2 = a.z + p.z, o3 = a.w + p.w;
+    if (thr16) {
+        const unsigned e = (unsigned)row * (unsigned)He + 4u * c;
+        const unsigned b0 = drop_bits(key, e >> 1), b1 = drop_bits(key, (e >> 1) + 1);
+        o0 *= drop_keep(b0, 0, thr16, inv_keep); o1 *= drop_keep(b0, 1, thr16, inv_keep);
+        o2 *= drop_keep(b1, 0, thr16, inv_keep); o3 *= drop_keep(b1, 1, thr16, inv_keep);
+    }
+    ((float4*)(x0 + row * He))[c] = make_float4(o0, o1, o2, o3);
+}
+
+// thread = (s, 4 columns): loops over the batch; writes dpatch (bf16), dpos (+= sum_b), dcls, patch-bias grad.
+__global__ void embed_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t* __restrict__ dpatch, float* dcls,
+                                          float* dpos, float* dpbias, int B, int np, int He, unsigned thr16,
+                                          float inv_keep, unsigned key) {
+    const int S = np + 1, h4 = He / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * h4) return;
+    const int c = t % h4, s = t / h4;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t row = (int64_t)b * S + s;
+        float4 d = ((const float4*)(dx0 + row * He))[c];
+        if (thr16) {
+            const unsigned e = (unsigned)row * (unsigned)He + 4u * c;
+            const unsigned b0 = drop_bits(key, e >> 1), b1 = drop_bits(key, (e >> 1) + 1);
+            d.x *= drop_keep(b0, 0, thr16, inv_keep); d.y *= drop_keep(b0, 1, thr16, inv_keep);
+            d.z *= drop_keep(b1, 0, thr16, inv_keep); d.w *= drop_keep(b1, 1, thr16, inv_keep);
+        }
+        a0 += d.x; a1 += d.y; a2 += d.z; a3 += d.w;
+        if (s > 0) ((uint2*)(dpatch + ((int64_t)b * np + s - 1) * He))[c] = make_uint2(pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
+    }
+    float* dp = dpos + (int64_t)s * He + 4 * c;
+    dp[0] += a0; dp[1] += a1; dp[2] += a2; dp[3] += a3;
+    if (s == 0) {
+        float* dc = dcls + 4 * c;
+        dc[0] += a0; dc[1] += a1; dc[2] += a2; dc[3] += a3;
+    } else {
+        float* db = dpbias + 4 * c;
+        atomicAdd(db + 0, a0); atomicAdd(db + 1, a1); atomicAdd(db + 2, a2); atomicAdd(db + 3, a3);
+    }
+}
+
+// ------------------------------------------------------------------------------- cast/drop + column sums
+// block = 64 column-lanes (4 columns each) x 4 row-lanes; grid.y strides 64-row chunks.
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ gin, int64_t ld, bf16_t* __restrict__ out,
+                                                     float* __restrict__ dbias, int M, int N, unsigned thr16,
+                                                     float inv_keep, unsigned key, const bf16_t* __restrict__ gelu_pre) {
+    __shared__ float red[4][256];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + cl) * 4;
+    const int r0 = blockIdx.y * 64;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (col < N) {
+        for (int r = r0 + rl; r < min(M, r0 + 64); r += 4) {
+            float4 d;
+            if (IN_F32) d = *(const float4*)((const float*)gin + (int64_t)r * ld + col);
+            else {
+                const uint2 u = *(const uint2*)((const bf16_t*)gin + (int64_t)r * ld + col);
+                d = make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
+            }
+            if (IN_F32) {
+                if (thr16) {
+                    const unsigned e = (unsigned)r * (unsigned)N + (unsigned)col;
+                    const unsigned b0 = drop_bits(key, e >> 1), b1 = drop_bits(key, (e >> 1) + 1);
+                    d.x *= drop_keep(b0, 0, thr16, inv_keep); d.y *= drop_keep(b0, 1, thr16, inv_keep);
+                    d.z *= drop_keep(b1, 0, thr16, inv_keep); d.w *= drop_keep(b1, 1, thr16, inv_keep);
+                }
+                if (gelu_pre) {   // backward of GELU: multiply by gelu'(saved pre-activation)
+                    const uint2 u = *(const uint2*)(gelu_pre + (int64_t)r * N + col);
+                    d.x *= gelu_erf_grad(bf2f(u.x & 0xffff)); d.y *= gelu_erf_grad(bf2f(u.x >> 16));
+                    d.z *= gelu_erf_grad(bf2f(u.y & 0xffff)); d.w *= gelu_erf_grad(bf2f(u.y >> 16));
+                }
+                const uint2 pk = make_uint2(pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
+                *(uint2*)(out + (int64_t)r * N + col) = pk;
+                // bias grad sums the values the GEMMs will actually see (bf16-rounded)
+                d = make_float4(bf2f(pk.x & 0xffff), bf2f(pk.x >> 16), bf2f(pk.y & 0xffff), bf2f(pk.y >> 16));
+            }
+            a0 += d.x; a1 += d.y; a2 += d.z; a3 += d.w;
+        }
+    }
+    red[rl][cl * 4 + 0] = a0; red[rl][cl * 4 + 1] = a1; red[rl][cl * 4 + 2] = a2; red[rl][cl * 4 + 3] = a3;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (dbias && c < N) atomicAdd(dbias + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------- decoder embeddings
+// position ids: cumsum(ids != pad) * (ids != pad) + pad over the decoder INPUT ids labels[:, :-1];
+// count = number of targets labels[:, 1:] != pad.  One thread per batch row (T <= 127).
+__global__ void dec_prepare_kernel(const int64_t* __restrict__ labels, int B, int L, int pad, int max_pos,
+                                   int* __restrict__ posids, float* count, int* err) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int T = L - 1;
+    int run = 0, cnt = 0;
+    for (int t = 0; t < T; ++t) {
+        const bool np = labels[(int64_t)b * L + t] != pad;
+        run += np;
+        int pid = np ? run + pad : pad;
+        if (pid >= max_pos) { *err = 1; pid = max_pos - 1; }   // HF would raise an index error here
+        posids[b * T + t] = pid;
+        cnt += labels[(int64_t)b * L + t + 1] != pad;
+    }
+    if (cnt) atomicAdd(count, (float)cnt);
+}
+
+__global__ void embed_gather_kernel(const int64_t* __restrict__ labels, int L, const int* __restrict__ posids,
+                                    const float* __restrict__ word, const float* __restrict__ type0,
+                                    const float* __restrict__ postab, float* __restrict__ out, int B, int T, int Hd) {
+    const int h4 = Hd / 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * T * h4) return;
+    const int c = t % h4;
+    const int64_t row = t / h4;
+    const int tt = row % T, b = (int)(row / T);
+    const int64_t id = labels[(int64_t)b * L + tt];
+    const int pid = posids[row];
+    const float4 w = ((const float4*)(word + id * Hd))[c], ty = ((const float4*)type0)[c];
+    const float4 p = ((const float4*)(postab + (int64_t)pid * Hd))[c];
+    ((float4*)(out + row * Hd))[c] = make_float4(w.x + ty.x + p.x, w.y + ty.y + p.y, w.z + ty.z + p.z, w.w + ty.w + p.w);
+}
+
+// one wave per 16 token rows; lanes over columns.  word/pos rows with padding_idx get no gradient
+// (nn.Embedding(padding_idx=pad) for BOTH tables: modeling_roberta.py:61,72-74).
+__global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const float* __restrict__ dsum, const int64_t* __restrict__ labels,
+                                                                int L, const int* __restrict__ posids, float* dword,
+                                                                float* dtype0, float* dpostab, int B, int T, int Hd, int pad) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t rbase = ((int64_t)blockIdx.x * 4 + w) * 16;
+    const int64_t rows = (int64_t)B * T;
+    for (int c = lane; c < Hd; c += 64) {
+        float acc = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = rbase + r;
+            if (row >= rows) break;
+            const float v = dsum[row * Hd + c];
+            acc += v;
+            const int tt = row % T, b = (int)(row / T);
+            const int64_t id = labels[(int64_t)b * L + tt];
+            const int pid = posids[row];
+            if (id != pad) atomicAdd(dword + id * Hd + c, v);
+            if (pid != pad) atomicAdd(dpostab + (int64_t)pid * Hd + c, v);
+        }
+        atomicAdd(dtype0 + c, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ cross entropy
+// one workgroup per token row; target = labels[b][t+1]; rows whose target is pad contribute nothing and
+// get a zero dlogits row.  dlogits = (softmax - onehot) / count, bf16, pad columns [V, ldl) zeroed.
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ labels,
+                                                 int L, int T, int V, int pad, const float* __restrict__ count,
+                                                 float* loss, bf16_t* __restrict__ dlogits) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = row / T, t = row - b * T;
+    const int64_t tgt = labels[(int64_t)b * L + t + 1];
+    const float* lr = logits + (int64_t)row * ldl;
+    bf16_t* dr = dlogits ? dlogits + (int64_t)row * ldl : nullptr;
+    const int n4 = (int)(ldl / 4);
+    if (tgt == pad) {
+        if (dr) for (int i = tid; i < n4; i += 256) ((uint2*)dr)[i] = make_uint2(0, 0);
+        return;
+    }
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, lr[i]);
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f;
+    for (int i = tid; i < V; i += 256) se += __expf(lr[i] - mx);
+    se = wave_sum(se);
+    if (lane == 0) red[4 + w] = se;
+    __syncthreads();
+    se = red[4] + red[5] + red[6] + red[7];
+    const float lse = mx + __logf(se);
+    const float inv_cnt = 1.f / *count;
+    if (tid == 0) atomicAdd(loss, (lse - lr[tgt]) * inv_cnt);
+    if (dr) {
+        for (int i = tid; i < n4; i += 256) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 4 * i + r;
+                v[r] = col < V ? (__expf(lr[col] - lse) - (col == tgt ? 1.f : 0.f)) * inv_cnt : 0.f;
+            }
+            ((uint2*)dr)[i] = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    }
+}
+
+__global__ void copy_logits_kernel(const float* __restrict__ logits, int64_t ldl, float* __restrict__ out, int64_t total, int V) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t row = t / V;
+    const int c = (int)(t - row * V);
+    out[t] = logits[row * ldl + c];
+}
+
+// ------------------------------------------------------------------------------------------ weight casts
+// 64x64 tile per workgroup; binary search of the tile index in the descriptor table.
+__global__ __launch_bounds__(256) void cast_weights_kernel(const KzvCastDesc* __restrict__ desc, int ndesc) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = ndesc - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].tile0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const KzvCastDesc d = desc[lo];
+    const int tl = bid - d.tile0;
+    const int tr = tl / d.tiles_c, tc = tl - tr * d.tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (r < d.rows && c < d.cols) {           // cols % 4 == 0 is checked on the host
+            v = *(const float4*)(d.src + (int64_t)r * d.cols + c);
+            *(uint2*)(d.dst + (int64_t)r * d.cols + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+        }
+        tile[ty + 16 * i][tx * 4 + 0] = v.x; tile[ty + 16 * i][tx * 4 + 1] = v.y;
+        tile[ty + 16 * i][tx * 4 + 2] = v.z; tile[ty + 16 * i][tx * 4 + 3] = v.w;
+    }
+    if (!d.dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 16 * i, r = r0 + tx * 4;   // output row = source column
+        if (c < d.cols && r < d.rows) {                     // rows % 4 == 0 checked on the host
+            const int lc = ty + 16 * i, lr = tx * 4;
+            *(uint2*)(d.dstT + (int64_t)c * d.ldT + r) =
+                make_uint2(pack_bf2(tile[lr][lc], tile[lr + 1][lc]), pack_bf2(tile[lr + 2][lc], tile[lr + 3][lc]));
+        }
+    }
+}
+
+inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace
+
+int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s) {
+    if (pw % 8 || W % pw || H % ph) return kzv_fail(KZV_E_ARG, "im2row: patch width must be a multiple of 8 and divide the image");
+    const int64_t total8 = (int64_t)B * C * H * W / 8;
+    hipLaunchKernelGGL(im2row_kernel, dim3(nblk(total8, 256)), dim3(256), 0, s, px, out, B, C, H, W, ph, pw, total8);
+    return kzv_check_launch("im2row");
+}
+
+int kzv_embed_assemble(const float* pe, const float* cls, const float* pos, float* x0, int B, int np, int He,
+                       float drop_p, uint32_t key, hipStream_t s) {
+    unsigned thr; float ik; kzv_drop_params(drop_p, &thr, &ik);
+    const int64_t total = (int64_t)B * (np + 1) * (He / 4);
+    hipLaunchKernelGGL(embed_assemble_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, pe, cls, pos, x0, B, np, He, thr, ik, key);
+    return kzv_check_launch("embed_assemble");
+}
+
+int kzv_embed_assemble_bwd(const float* dx0, bf16_t* dpatch, float* dcls, float* dpos, float* dpbias, int B, int np, int He,
+                           float drop_p, uint32_t key, hipStream_t s) {
+    unsigned thr; float ik; kzv_drop_params(drop_p, &thr, &ik);
+    const int total = (np + 1) * (He / 4);
+    hipLaunchKernelGGL(embed_assemble_bwd_kernel, dim3(nblk(total, 64)), dim3(64), 0, s, dx0, dpatch, dcls, dpos, dpbias, B, np, He, thr, ik, key);
+    return kzv_check_launch("embed_assemble_bwd");
+}
+
+int kzv_cast_drop_colsum(const float* g, bf16_t* out, float* dbias, int M, int N, float drop_p, uint32_t key, hipStream_t s,
+                         const bf16_t* gelu_pre) {
+    if (N % 4) return kzv_fail(KZV_E_ARG, "cast_drop_colsum: N %% 4");
+    unsigned thr; float ik; kzv_drop_params(drop_p, &thr, &ik);
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3((N + 255) / 256, (M + 63) / 64), dim3(256), 0, s, (const void*)g, (int64_t)N, out, dbias, M, N, thr, ik, key, gelu_pre);
+    return kzv_check_launch("cast_drop_colsum");
+}
+
+int kzv_colsum_bf16(const bf16_t* g, int64_t ld, float* dbias, int M, int N, hipStream_t s) {
+    if (N % 4 || ld % 4) return kzv_fail(KZV_E_ARG, "colsum_bf16: N, ld %% 4");
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3((N + 255) / 256, (M + 63) / 64), dim3(256), 0, s, (const void*)g, ld, (bf16_t*)nullptr, dbias, M, N, 0u, 1.f, 0u, (const bf16_t*)nullptr);
+    return kzv_check_launch("colsum_bf16");
+}
+
+int kzv_dec_prepare(const int64_t* labels, int B, int L, int pad, int max_pos, int* posids, float* count, int* err, hipStream_t s) {
+    hipLaunchKernelGGL(dec_prepare_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, labels, B, L, pad, max_pos, posids, count, err);
+    return kzv_check_launch("dec_prepare");
+}
+
+int kzv_embed_gather(const int64_t* labels, int L, const int* posids, const float* word, const float* type0,
+                     const float* postab, float* out, int B, int T, int Hd, hipStream_t s) {
+    const int64_t total = (int64_t)B * T * (Hd / 4);
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, labels, L, posids, word, type0, postab, out, B, T, Hd);
+    return kzv_check_launch("embed_gather");
+}
+
+int kzv_embed_scatter_bwd(const float* dsum, const int64_t* labels, int L, const int* posids, float* dword, float* dtype0,
+                          float* dpostab, int B, int T, int Hd, int pad, hipStream_t s) {
+    const int64_t rows = (int64_t)B * T;
+    hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(nblk(rows, 64)), dim3(256), 0, s, dsum, labels, L, posids, dword, dtype0, dpostab, B, T, Hd, pad);
+    return kzv_check_launch("embed_scatter_bwd");
+}
+
+int kzv_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int L, int B, int T, int V, int pad,
+                   const float* count, float* loss, bf16_t* dlogits, hipStream_t s) {
+    if (ldl % 4) return kzv_fail(KZV_E_ARG, "ce: ldl %% 4");
+    hipLaunchKernelGGL(ce_kernel, dim3(B * T), dim3(256), 0, s, logits, ldl, labels, L, T, V, pad, count, loss, dlogits);
+    return kzv_check_launch("ce_fwd_bwd");
+}
+
+int kzv_copy_logits(const float* logits, int64_t ldl, float* out, int rows, int V, hipStream_t s) {
+    const int64_t total = (int64_t)rows * V;
+    hipLaunchKernelGGL(copy_logits_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, logits, ldl, out, total, V);
+    return kzv_check_launch("copy_logits");
+}
+
+int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s) {
+    hipLaunchKernelGGL(cast_weights_kernel, dim3(total_tiles), dim3(256), 0, s, d_desc, ndesc);
+    return kzv_check_launch("cast_weights");
+}

@@ -1,0 +1,75 @@
+// Shared device helpers for the kzv HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA 16x16x32 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;   // one ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // one MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+typedef __attribute__((ext_vector_type(2))) float f2_t;
+
+#define KZV_LDS __attribute__((address_space(3)))
+#define KZV_GLB __attribute__((address_space(1)))
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __builtin_bit_cast(float, (unsigned)x << 16); }
+// round-to-nearest-even pair conversion -> v_cvt_pk_bf16_f32 (lo in bits 0..15)
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    bf2_t v = __builtin_convertvector((f2_t){lo, hi}, bf2_t);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)(pack_bf2(x, 0.f) & 0xffffu); }
+
+// ---- wave64 reductions ------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- counter-based dropout bits ------------------------------------------------
+// One 32-bit hash per PAIR of elements; each element takes 16 bits and is KEPT iff bits >= thr16
+// (thr16 = round(p * 65536)), so P(drop) = thr16/65536.  The same (key, pair index) is recomputed in
+// backward, so no mask is stored.  key = kzv_drop_key(seed, site) mixes the step seed with a
+// per-call-site id on the host.
+__device__ __forceinline__ unsigned kzv_hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_bits(unsigned key, unsigned pair_idx) {
+    return kzv_hash32(pair_idx * 0x9E3779B9U + key);
+}
+// keep-multiplier for element `which` (0/1) of a pair
+__device__ __forceinline__ float drop_keep(unsigned bits, int which, unsigned thr16, float inv_keep) {
+    unsigned r = which ? (bits >> 16) : (bits & 0xffffu);
+    return r >= thr16 ? inv_keep : 0.f;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware block remap (bijective for any grid size): blocks that share an XCD under round-robin
+// dispatch (id % 8) get a contiguous chunk of logical tile ids, so neighbours share L2 lines.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const KZV_GLB void*)g, (KZV_LDS void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x4 lds_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((KZV_LDS bf16x4*)p);
+}

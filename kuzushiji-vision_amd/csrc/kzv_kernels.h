@@ -1,0 +1,41 @@
+// Internal launcher API (C++ linkage) used by model.cpp; the per-op C ABI in include/kzv.h wraps a subset.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kzv_common.h"
+
+// layernorm.hip
+int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* stats,
+                  int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s);
+int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
+                  int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
+                  float drop_p, uint32_t drop_key, hipStream_t s);
+
+// elementwise.hip
+int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s);
+int kzv_embed_assemble(const float* patch_emb, const float* cls, const float* pos, float* x0, int B, int np, int He,
+                       float drop_p, uint32_t key, hipStream_t s);
+int kzv_embed_assemble_bwd(const float* dx0, bf16_t* dpatch, float* dcls, float* dpos, float* dpatch_bias, int B, int np,
+                           int He, float drop_p, uint32_t key, hipStream_t s);
+int kzv_cast_drop_colsum(const float* g, bf16_t* out, float* dbias, int M, int N, float drop_p, uint32_t key, hipStream_t s,
+                         const bf16_t* gelu_pre = nullptr);
+int kzv_colsum_bf16(const bf16_t* g, int64_t ld, float* dbias, int M, int N, hipStream_t s);
+int kzv_dec_prepare(const int64_t* labels, int B, int L, int pad, int max_pos, int* posids, float* count, int* err, hipStream_t s);
+int kzv_embed_gather(const int64_t* labels, int L, const int* posids, const float* word, const float* type0,
+                     const float* postab, float* out, int B, int T, int Hd, hipStream_t s);
+int kzv_embed_scatter_bwd(const float* dsum, const int64_t* labels, int L, const int* posids, float* dword, float* dtype0,
+                          float* dpostab, int B, int T, int Hd, int pad, hipStream_t s);
+int kzv_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int L, int B, int T, int V, int pad,
+                   const float* count, float* loss, bf16_t* dlogits, hipStream_t s);
+int kzv_copy_logits(const float* logits, int64_t ldl, float* out, int rows, int V, hipStream_t s);
+
+struct KzvCastDesc {         // one 2-D fp32 weight -> bf16 copy (+ optional transposed copy)
+    const float* src; bf16_t* dst; bf16_t* dstT;
+    int rows, cols; int64_t ldT; int tile0, tiles_c;
+};
+int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s);
+
+// optim.hip
+int kzv_sqnorm(const float* g, int64_t n, float* out1, float* scratch, hipStream_t s);
+
+// attention.hip : see include/kzv.h (kzv_attn_fwd / kzv_attn_bwd)

@@ -1,0 +1,197 @@
+// LayerNorm forward / backward (fp32 statistics, eps inside the rsqrt, one wave64 per row).
+// Replaces nn.LayerNorm(eps=1e-12) at: ViTLayer.layernorm_before/after (HF modeling_vit.py:261-262),
+// ViTEncoder.layernorm (src/models/trocr_model.py:152,197), RoBERTa post-LNs
+// (HF modeling_roberta.py:333,339,391,397), embeddings LN (:64,120), LM-head LN (:883,890).
+//
+// HBM-bound: forward reads x once (row kept in registers), writes bf16 (+ optional fp32);
+// backward reads dy + x once, writes dx once; gamma/beta gradients are reduced per workgroup in
+// registers/LDS and leave with one float atomic per column per workgroup.
+//
+// Row remap (`seq`, `drop_first`): the encoder's final LN output drops the CLS token
+// (trocr_model.py:200), so output row = row - row/seq - 1 and rows with row % seq == 0 are skipped.
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "kzv_kernels.h"
+
+namespace {
+
+constexpr int MAXC = 8;  // float4 chunks per lane -> H <= 2048
+
+struct LnFwd {
+    const float* x; const float* gamma; const float* beta; bf16_t* y16; float* y32; float* stats;
+    int rows, H, seq, drop_first; float eps;
+    unsigned thr16; float inv_keep; unsigned key;
+};
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nc = p.H >> 2;
+    const float4* xr = (const float4*)(p.x + (int64_t)row * p.H);
+    float4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) { v[c] = xr[i]; s += v[c].x + v[c].y + v[c].z + v[c].w; }
+    }
+    const float mean = wave_sum(s) / (float)p.H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)p.H + p.eps);
+    if (p.stats && lane == 0) { p.stats[2 * row] = mean; p.stats[2 * row + 1] = rstd; }
+    int orow = row;
+    if (p.drop_first) {
+        if (row % p.seq == 0) return;
+        orow = row - row / p.seq - 1;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) {
+            const float4 gm = ((const float4*)p.gamma)[i], bt = ((const float4*)p.beta)[i];
+            float o0 = (v[c].x - mean) * rstd * gm.x + bt.x, o1 = (v[c].y - mean) * rstd * gm.y + bt.y;
+            float o2 = (v[c].z - mean) * rstd * gm.z + bt.z, o3 = (v[c].w - mean) * rstd * gm.w + bt.w;
+            if (p.thr16) {
+                const unsigned e = (unsigned)orow * (unsigned)p.H + 4u * i;
+                const unsigned b0 = drop_bits(p.key, e >> 1), b1 = drop_bits(p.key, (e >> 1) + 1);
+                o0 *= drop_keep(b0, 0, p.thr16, p.inv_keep); o1 *= drop_keep(b0, 1, p.thr16, p.inv_keep);
+                o2 *= drop_keep(b1, 0, p.thr16, p.inv_keep); o3 *= drop_keep(b1, 1, p.thr16, p.inv_keep);
+            }
+            if (p.y16) ((uint2*)(p.y16 + (int64_t)orow * p.H))[i] = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+            if (p.y32) ((float4*)(p.y32 + (int64_t)orow * p.H))[i] = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+struct LnBwd {
+    const void* dy; const float* x; const float* stats; const float* gamma;
+    float* dx; float* dgamma; float* dbeta;
+    int rows, H, seq, drop_first, dy_f32, accumulate;
+    unsigned thr16; float inv_keep; unsigned key;
+};
+
+constexpr int BWD_ROWS = 32;  // rows per workgroup (4 waves x 8)
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nc = p.H >> 2;
+    float4 dg[MAXC], db[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { dg[c] = make_float4(0, 0, 0, 0); db[c] = make_float4(0, 0, 0, 0); }
+    const float invH = 1.f / (float)p.H;
+    for (int rr = 0; rr < BWD_ROWS / 4; ++rr) {
+        const int row = blockIdx.x * BWD_ROWS + rr * 4 + w;
+        if (row >= p.rows) break;
+        int drow = row;
+        bool has_dy = true;
+        if (p.drop_first) {
+            if (row % p.seq == 0) has_dy = false;
+            drow = row - row / p.seq - 1;
+        }
+        const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
+        const float4* xr = (const float4*)(p.x + (int64_t)row * p.H);
+        float4 xh[MAXC], gy[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int i = lane + c * 64;
+            if (i < nc) {
+                const float4 xv = xr[i];
+                float4 d = make_float4(0, 0, 0, 0);
+                if (has_dy) {
+                    if (p.dy_f32) d = ((const float4*)((const float*)p.dy + (int64_t)drow * p.H))[i];
+                    else {
+                        const uint2 u = ((const uint2*)((const bf16_t*)p.dy + (int64_t)drow * p.H))[i];
+                        d = make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
+                    }
+                    if (p.thr16) {
+                        const unsigned e = (unsigned)drow * (unsigned)p.H + 4u * i;
+                        const unsigned b0 = drop_bits(p.key, e >> 1), b1 = drop_bits(p.key, (e >> 1) + 1);
+                        d.x *= drop_keep(b0, 0, p.thr16, p.inv_keep); d.y *= drop_keep(b0, 1, p.thr16, p.inv_keep);
+                        d.z *= drop_keep(b1, 0, p.thr16, p.inv_keep); d.w *= drop_keep(b1, 1, p.thr16, p.inv_keep);
+                    }
+                }
+                const float4 gm = ((const float4*)p.gamma)[i];
+                xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                gy[c] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                s1 += gy[c].x + gy[c].y + gy[c].z + gy[c].w;
+                s2 += gy[c].x * xh[c].x + gy[c].y * xh[c].y + gy[c].z * xh[c].z + gy[c].w * xh[c].w;
+                dg[c].x += d.x * xh[c].x; dg[c].y += d.y * xh[c].y; dg[c].z += d.z * xh[c].z; dg[c].w += d.w * xh[c].w;
+                db[c].x += d.x; db[c].y += d.y; db[c].z += d.z; db[c].w += d.w;
+            }
+        }
+        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+        float4* dxr = (float4*)(p.dx + (int64_t)row * p.H);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int i = lane + c * 64;
+            if (i < nc) {
+                float4 o = make_float4(rstd * (gy[c].x - m1 - xh[c].x * m2), rstd * (gy[c].y - m1 - xh[c].y * m2),
+                                       rstd * (gy[c].z - m1 - xh[c].z * m2), rstd * (gy[c].w - m1 - xh[c].w * m2));
+                if (p.accumulate) { const float4 a = dxr[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                dxr[i] = o;
+            }
+        }
+    }
+    // workgroup reduction of the gamma/beta partials, then one atomic per column
+    float4* sg = (float4*)smem + (w * 2) * nc;
+    float4* sb = sg + nc;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nc) { sg[i] = dg[c]; sb[i] = db[c]; }
+    }
+    __syncthreads();
+    const float* sf = (const float*)smem;
+    for (int col = threadIdx.x; col < p.H; col += 256) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { a += sf[(ww * 2) * p.H + col]; b += sf[(ww * 2 + 1) * p.H + col]; }
+        atomicAdd(p.dgamma + col, a);
+        atomicAdd(p.dbeta + col, b);
+    }
+}
+
+}  // namespace
+
+int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* stats,
+                  int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s) {
+    if (!x || !gamma || !beta || rows <= 0) return kzv_fail(KZV_E_ARG, "layernorm_fwd: null/empty");
+    if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
+    LnFwd p{x, gamma, beta, (bf16_t*)y16, y32, stats, rows, H, seq > 0 ? seq : 1, drop_first, eps, 0, 1.f, drop_key};
+    kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+    return kzv_check_launch("layernorm_fwd");
+}
+
+int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
+                  int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
+                  float drop_p, uint32_t drop_key, hipStream_t s) {
+    if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || rows <= 0) return kzv_fail(KZV_E_ARG, "layernorm_bwd: null/empty");
+    if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
+    LnBwd p{dy, x, stats, gamma, dx, dgamma, dbeta, rows, H, seq > 0 ? seq : 1, drop_first, dy_is_f32, accumulate_dx, 0, 1.f, drop_key};
+    kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + BWD_ROWS - 1) / BWD_ROWS), dim3(256), 8 * H * sizeof(float), s, p);
+    return kzv_check_launch("layernorm_bwd");
+}
+
+extern "C" int kzv_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                                 float* stats, int rows, int H, float eps, void* stream) {
+    return kzv_ln_fwd_ex(x, gamma, beta, y_bf16, y_f32, stats, rows, H, eps, 1, 0, 0.f, 0, (hipStream_t)stream);
+}
+
+extern "C" int kzv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma,
+                                 float* dx, int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, void* stream) {
+    return kzv_ln_bwd_ex(dy, dy_is_f32, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, rows, H, 1, 0, 0.f, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,587 @@
+// Model handle: parameter table, workspace plan, forward / backward schedules of the TrOCR training step.
+//
+// forward  = TrOCRModel.forward training branch (src/models/trocr_model.py:258-297):
+//            ViTEncoder.forward (:169-202, 12 x HF ViTLayer pre-LN) -> encoder_decoder_proj (:269) ->
+//            RobertaForCausalLM teacher-forced (HF modeling_roberta.py:75-122, 421-464, 877-893) -> CE (:292)
+// backward = what loss.backward() does for that graph, hand-derived (no autograd), every matmul on the
+//            MFMA GEMMs of gemm.hip, everything else fused into their epilogues or the HBM-bound kernels.
+//
+// Numeric policy (scripts/train_trocr.py:165-176 "bf16-mixed"): fp32 master weights and gradients, fp32
+// residual stream / LayerNorm / softmax / loss, bf16 GEMM operands with fp32 accumulation.
+#include "kzv_host.h"
+#include "kzv_kernels.h"
+#include "../../include/kzv.h"
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct PEntry { std::string name; int64_t off, rows, cols; };
+
+inline int64_t align_up(int64_t n, int64_t a) { return (n + a - 1) / a * a; }
+
+struct EncLayerP { int64_t ln1w, ln1b, qkvw, qkvb, ow, ob, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b; };
+struct DecLayerP { int64_t qkvw, qkvb, ow, ob, ln1w, ln1b, cqw, cqb, cow, cob, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b, ln3w, ln3b; };
+struct W16 { bf16_t* w; bf16_t* wt; int64_t ldt; };   // bf16 copy [N,K] and transposed copy [K, ldt]
+
+struct EncAct {
+    float *x_in, *x_mid, *st1, *st2, *lse;
+    bf16_t *ln1, *qkv, *ctx, *ln2, *pre, *act;
+};
+struct DecAct {
+    float *s1, *x1, *s2, *x2, *s3, *x3, *st1, *st2, *st3, *lse_sa, *lse_ca;
+    bf16_t *qkv, *ctx, *x1h, *cq, *cctx, *x2h, *pre, *act, *x3h;
+};
+
+}  // namespace
+
+struct kzv_model {
+    kzv_config c;
+    int np, Se, PD, He, Fe, Hd, Fd, V, Vp, Le, Ld;
+    bool has_proj;
+    std::vector<PEntry> table;
+    int64_t total = 0;
+    // parameter offsets
+    int64_t patch_w, patch_b, cls, pos, lnf_w, lnf_b, proj_w, proj_b, word, dpos, dtype, eln_w, eln_b, ckv_w, ckv_b,
+        hd_w, hd_b, hln_w, hln_b, hbias;
+    std::vector<EncLayerP> ep;
+    std::vector<DecLayerP> dp;
+    // bound state
+    float* P = nullptr; float* G = nullptr; char* ws = nullptr; int64_t ws_bytes = 0;
+    int B = 0, L = 0, T = 0;
+    bool bound = false, have_fwd = false, train = false;
+    uint64_t seed = 0;
+    const int64_t* labels = nullptr;
+    // workspace pointers
+    KzvCastDesc* d_desc = nullptr; int ndesc = 0, cast_tiles = 0;
+    std::vector<KzvCastDesc> h_desc;
+    W16 w_patch, w_proj, w_word, w_ckv, w_hd;
+    std::vector<W16> w_eqkv, w_eo, w_efc1, w_efc2, w_dqkv, w_do, w_dcq, w_dco, w_dfc1, w_dfc2;
+    bf16_t *patches, *enc_out, *proj_out, *crosskv, *xd0h, *hd_pre, *hd_ln, *dlogits;
+    float *pe32, *x_last, *stf, *emb_sum, *emb_st, *xd0, *hd_gelu, *hd_st, *logits, *count, *loss_acc;
+    int *posids, *err;
+    std::vector<EncAct> ea;
+    std::vector<DecAct> da;
+    // backward scratch
+    float *dx_e, *dx_d, *dsum_d;
+    bf16_t *dy_e, *dbig_e, *dh_e, *dqkv_e, *dctx_e, *dpatch, *denc_out, *denc, *dckv, *dy_d, *dbig_d, *dqkv_d, *dctx_d, *dq_d, *dhln;
+};
+
+namespace {
+
+int64_t add_param(kzv_model* m, const std::string& name, int64_t rows, int64_t cols) {
+    const int64_t off = m->total;
+    m->table.push_back({name, off, rows, cols});
+    m->total += align_up(rows * cols, 64);
+    return off;
+}
+
+// MUST match kzv/params.py::param_table (tests/test_capi_cpu.py checks name/offset/shape equality)
+void build_param_table(kzv_model* m) {
+    const int He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
+    m->patch_w = add_param(m, "enc.patch.w", He, m->PD);
+    m->patch_b = add_param(m, "enc.patch.b", He, 1);
+    m->cls = add_param(m, "enc.cls", He, 1);
+    m->pos = add_param(m, "enc.pos", m->Se, He);
+    m->ep.resize(m->Le);
+    for (int i = 0; i < m->Le; ++i) {
+        const std::string p = "enc." + std::to_string(i) + ".";
+        EncLayerP& e = m->ep[i];
+        e.ln1w = add_param(m, p + "ln1.w", He, 1); e.ln1b = add_param(m, p + "ln1.b", He, 1);
+        e.qkvw = add_param(m, p + "qkv.w", 3 * He, He); e.qkvb = add_param(m, p + "qkv.b", 3 * He, 1);
+        e.ow = add_param(m, p + "o.w", He, He); e.ob = add_param(m, p + "o.b", He, 1);
+        e.ln2w = add_param(m, p + "ln2.w", He, 1); e.ln2b = add_param(m, p + "ln2.b", He, 1);
+        e.fc1w = add_param(m, p + "fc1.w", Fe, He); e.fc1b = add_param(m, p + "fc1.b", Fe, 1);
+        e.fc2w = add_param(m, p + "fc2.w", He, Fe); e.fc2b = add_param(m, p + "fc2.b", He, 1);
+    }
+    m->lnf_w = add_param(m, "enc.lnf.w", He, 1); m->lnf_b = add_param(m, "enc.lnf.b", He, 1);
+    if (m->has_proj) { m->proj_w = add_param(m, "proj.w", Hd, He); m->proj_b = add_param(m, "proj.b", Hd, 1); }
+    m->word = add_param(m, "dec.word", m->V, Hd);
+    m->dpos = add_param(m, "dec.pos", m->c.max_pos, Hd);
+    m->dtype = add_param(m, "dec.type", m->c.type_vocab, Hd);
+    m->eln_w = add_param(m, "dec.emb_ln.w", Hd, 1); m->eln_b = add_param(m, "dec.emb_ln.b", Hd, 1);
+    m->ckv_w = add_param(m, "dec.cross_kv.w", (int64_t)m->Ld * 2 * Hd, Hd);
+    m->ckv_b = add_param(m, "dec.cross_kv.b", (int64_t)m->Ld * 2 * Hd, 1);
+    m->dp.resize(m->Ld);
+    for (int i = 0; i < m->Ld; ++i) {
+        const std::string p = "dec." + std::to_string(i) + ".";
+        DecLayerP& d = m->dp[i];
+        d.qkvw = add_param(m, p + "sa_qkv.w", 3 * Hd, Hd); d.qkvb = add_param(m, p + "sa_qkv.b", 3 * Hd, 1);
+        d.ow = add_param(m, p + "sa_o.w", Hd, Hd); d.ob = add_param(m, p + "sa_o.b", Hd, 1);
+        d.ln1w = add_param(m, p + "sa_ln.w", Hd, 1); d.ln1b = add_param(m, p + "sa_ln.b", Hd, 1);
+        d.cqw = add_param(m, p + "ca_q.w", Hd, Hd); d.cqb = add_param(m, p + "ca_q.b", Hd, 1);
+        d.cow = add_param(m, p + "ca_o.w", Hd, Hd); d.cob = add_param(m, p + "ca_o.b", Hd, 1);
+        d.ln2w = add_param(m, p + "ca_ln.w", Hd, 1); d.ln2b = add_param(m, p + "ca_ln.b", Hd, 1);
+        d.fc1w = add_param(m, p + "fc1.w", Fd, Hd); d.fc1b = add_param(m, p + "fc1.b", Fd, 1);
+        d.fc2w = add_param(m, p + "fc2.w", Hd, Fd); d.fc2b = add_param(m, p + "fc2.b", Hd, 1);
+        d.ln3w = add_param(m, p + "out_ln.w", Hd, 1); d.ln3b = add_param(m, p + "out_ln.b", Hd, 1);
+    }
+    m->hd_w = add_param(m, "head.dense.w", Hd, Hd); m->hd_b = add_param(m, "head.dense.b", Hd, 1);
+    m->hln_w = add_param(m, "head.ln.w", Hd, 1); m->hln_b = add_param(m, "head.ln.b", Hd, 1);
+    m->hbias = add_param(m, "head.bias", m->V, 1);
+}
+
+// ---- workspace bump allocator: pass 1 (base == nullptr) only measures ------------------------------
+struct Bump {
+    char* base; int64_t off = 0;
+    template <class T> T* take(int64_t n) {
+        off = align_up(off, 256);
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * (int64_t)sizeof(T);
+        return p;
+    }
+};
+
+W16 take_w(kzv_model* m, Bump& b, int64_t woff, int64_t N, int64_t K, bool need_t) {
+    W16 w;
+    w.w = b.take<bf16_t>(N * K);
+    w.ldt = align_up(N, 64);
+    w.wt = need_t ? b.take<bf16_t>(K * w.ldt) : nullptr;
+    KzvCastDesc d;
+    d.src = m->P ? m->P + woff : nullptr; d.dst = w.w; d.dstT = w.wt; d.rows = (int)N; d.cols = (int)K; d.ldT = w.ldt;
+    d.tiles_c = (int)((K + 63) / 64);
+    d.tile0 = m->cast_tiles;
+    m->cast_tiles += (int)((N + 63) / 64) * d.tiles_c;
+    m->h_desc.push_back(d);
+    return w;
+}
+
+int64_t plan(kzv_model* m, char* base, int B, int L) {
+    Bump b{base};
+    const int T = L - 1;
+    const int64_t Me = (int64_t)B * m->Se, Mp = (int64_t)B * m->np, Md = (int64_t)B * T;
+    const int He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
+    m->h_desc.clear(); m->cast_tiles = 0;
+    // bf16 weight copies first: this whole region is zeroed at bind (transposed-copy padding stays zero)
+    m->w_patch = take_w(m, b, m->patch_w, He, m->PD, false);
+    auto vec = [&](std::vector<W16>& v, int n) { v.resize(n); };
+    vec(m->w_eqkv, m->Le); vec(m->w_eo, m->Le); vec(m->w_efc1, m->Le); vec(m->w_efc2, m->Le);
+    for (int i = 0; i < m->Le; ++i) {
+        m->w_eqkv[i] = take_w(m, b, m->ep[i].qkvw, 3 * He, He, true);
+        m->w_eo[i] = take_w(m, b, m->ep[i].ow, He, He, true);
+        m->w_efc1[i] = take_w(m, b, m->ep[i].fc1w, Fe, He, true);
+        m->w_efc2[i] = take_w(m, b, m->ep[i].fc2w, He, Fe, true);
+    }
+    if (m->has_proj) m->w_proj = take_w(m, b, m->proj_w, Hd, He, true);
+    m->w_word = take_w(m, b, m->word, m->V, Hd, true);
+    m->w_ckv = take_w(m, b, m->ckv_w, (int64_t)m->Ld * 2 * Hd, Hd, true);
+    vec(m->w_dqkv, m->Ld); vec(m->w_do, m->Ld); vec(m->w_dcq, m->Ld); vec(m->w_dco, m->Ld); vec(m->w_dfc1, m->Ld); vec(m->w_dfc2, m->Ld);
+    for (int i = 0; i < m->Ld; ++i) {
+        m->w_dqkv[i] = take_w(m, b, m->dp[i].qkvw, 3 * Hd, Hd, true);
+        m->w_do[i] = take_w(m, b, m->dp[i].ow, Hd, Hd, true);
+        m->w_dcq[i] = take_w(m, b, m->dp[i].cqw, Hd, Hd, true);
+        m->w_dco[i] = take_w(m, b, m->dp[i].cow, Hd, Hd, true);
+        m->w_dfc1[i] = take_w(m, b, m->dp[i].fc1w, Fd, Hd, true);
+        m->w_dfc2[i] = take_w(m, b, m->dp[i].fc2w, Hd, Fd, true);
+    }
+    m->w_hd = take_w(m, b, m->hd_w, Hd, Hd, true);
+    m->ndesc = (int)m->h_desc.size();
+    m->d_desc = b.take<KzvCastDesc>(m->ndesc);
+    const int64_t weights_end = b.off;
+
+    // scalars
+    m->count = b.take<float>(64); m->loss_acc = m->count + 1; m->err = (int*)(m->count + 2);
+    m->posids = b.take<int>(Md);
+    // encoder activations
+    m->patches = b.take<bf16_t>(Mp * m->PD);
+    m->pe32 = b.take<float>(Mp * He);
+    m->ea.resize(m->Le);
+    const int64_t lse_e = (int64_t)B * m->c.enc_heads * m->Se;
+    for (int i = 0; i < m->Le; ++i) {
+        EncAct& a = m->ea[i];
+        a.x_in = b.take<float>(Me * He); a.x_mid = b.take<float>(Me * He);
+        a.st1 = b.take<float>(Me * 2); a.st2 = b.take<float>(Me * 2); a.lse = b.take<float>(lse_e);
+        a.ln1 = b.take<bf16_t>(Me * He); a.qkv = b.take<bf16_t>(Me * 3 * He); a.ctx = b.take<bf16_t>(Me * He);
+        a.ln2 = b.take<bf16_t>(Me * He); a.pre = b.take<bf16_t>(Me * Fe); a.act = b.take<bf16_t>(Me * Fe);
+    }
+    m->x_last = b.take<float>(Me * He); m->stf = b.take<float>(Me * 2);
+    m->enc_out = b.take<bf16_t>(Mp * He);
+    m->proj_out = m->has_proj ? b.take<bf16_t>(Mp * Hd) : m->enc_out;
+    // decoder activations
+    const int64_t CK = (int64_t)m->Ld * 2 * Hd;
+    m->crosskv = b.take<bf16_t>(Mp * CK);
+    m->emb_sum = b.take<float>(Md * Hd); m->emb_st = b.take<float>(Md * 2);
+    m->xd0 = b.take<float>(Md * Hd); m->xd0h = b.take<bf16_t>(Md * Hd);
+    m->da.resize(m->Ld);
+    const int64_t lse_d = (int64_t)B * m->c.dec_heads * T;
+    for (int i = 0; i < m->Ld; ++i) {
+        DecAct& a = m->da[i];
+        a.s1 = b.take<float>(Md * Hd); a.x1 = b.take<float>(Md * Hd); a.s2 = b.take<float>(Md * Hd); a.x2 = b.take<float>(Md * Hd);
+        a.s3 = b.take<float>(Md * Hd); a.x3 = b.take<float>(Md * Hd);
+        a.st1 = b.take<float>(Md * 2); a.st2 = b.take<float>(Md * 2); a.st3 = b.take<float>(Md * 2);
+        a.lse_sa = b.take<float>(lse_d); a.lse_ca = b.take<float>(lse_d);
+        a.qkv = b.take<bf16_t>(Md * 3 * Hd); a.ctx = b.take<bf16_t>(Md * Hd); a.x1h = b.take<bf16_t>(Md * Hd);
+        a.cq = b.take<bf16_t>(Md * Hd); a.cctx = b.take<bf16_t>(Md * Hd); a.x2h = b.take<bf16_t>(Md * Hd);
+        a.pre = b.take<bf16_t>(Md * Fd); a.act = b.take<bf16_t>(Md * Fd); a.x3h = b.take<bf16_t>(Md * Hd);
+    }
+    m->hd_pre = b.take<bf16_t>(Md * Hd); m->hd_gelu = b.take<float>(Md * Hd); m->hd_st = b.take<float>(Md * 2);
+    m->hd_ln = b.take<bf16_t>(Md * Hd);
+    m->logits = b.take<float>(Md * m->Vp); m->dlogits = b.take<bf16_t>(Md * m->Vp);
+    // backward scratch
+    m->dx_e = b.take<float>(Me * He); m->dy_e = b.take<bf16_t>(Me * He); m->dbig_e = b.take<bf16_t>(Me * Fe);
+    m->dh_e = b.take<bf16_t>(Me * He); m->dqkv_e = b.take<bf16_t>(Me * 3 * He); m->dctx_e = b.take<bf16_t>(Me * He);
+    m->dpatch = b.take<bf16_t>(Mp * He); m->denc_out = b.take<bf16_t>(Mp * He);
+    m->denc = m->has_proj ? b.take<bf16_t>(Mp * Hd) : m->denc_out;
+    m->dckv = b.take<bf16_t>(Mp * CK);
+    m->dx_d = b.take<float>(Md * Hd); m->dsum_d = b.take<float>(Md * Hd);
+    m->dy_d = b.take<bf16_t>(Md * Hd); m->dbig_d = b.take<bf16_t>(Md * Fd); m->dqkv_d = b.take<bf16_t>(Md * 3 * Hd);
+    m->dctx_d = b.take<bf16_t>(Md * Hd); m->dq_d = b.take<bf16_t>(Md * Hd); m->dhln = b.take<bf16_t>(Md * Hd);
+    (void)weights_end;
+    return align_up(b.off, 256);
+}
+
+// dropout site ids (distinct hash keys per call site and layer)
+enum { SITE_ENC_EMB = 1, SITE_ENC_L = 16, SITE_DEC_EMB = 1000, SITE_DEC_L = 1016 };
+inline uint32_t key(const kzv_model* m, uint32_t site) { return kzv_drop_key(m->seed, site); }
+inline float dp(const kzv_model* m, float p) { return m->train ? p : 0.f; }
+
+#define KZV_TRY(expr) do { int rc__ = (expr); if (rc__ != KZV_OK) return rc__; } while (0)
+
+int gemm(const bf16_t* A, int64_t lda, const W16& w, bool transposed, int M, int N, int K, int n_valid, const float* bias,
+         void* C, int64_t ldc, int epi, hipStream_t s, const float* resid = nullptr, void* aux = nullptr, int64_t ldaux = 0,
+         float drop_p = 0.f, uint32_t drop_key = 0) {
+    kzv_gemm_nt_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda;
+    a.B = transposed ? w.wt : w.w; a.ldb = transposed ? w.ldt : K;
+    a.C = C; a.ldc = ldc; a.bias = bias; a.resid = resid; a.ldr = ldc; a.aux = aux; a.ldaux = ldaux;
+    a.M = M; a.N = N; a.K = K; a.n_valid = n_valid; a.drop_p = drop_p; a.drop_key = drop_key;
+    return kzv_gemm_nt(&a, epi, s);
+}
+
+int wgrad(const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok, int N, int K, int n_store, hipStream_t s) {
+    kzv_gemm_tn_args a;
+    memset(&a, 0, sizeof(a));
+    a.P = dY; a.ldp = ldp; a.Q = X; a.ldq = ldq; a.OUT = dW; a.ldo = K; a.Mtok = Mtok; a.N = N; a.K = K; a.n_store = n_store;
+    return kzv_gemm_tn(&a, s);
+}
+
+int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, const bf16_t* K, const bf16_t* V, int64_t ldkv,
+         bf16_t* O, int64_t ldo, float* LSE, const bf16_t* dO, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int heads, int Sq, int Sk,
+         float drop_p, uint32_t drop_key, hipStream_t s) {
+    kzv_attn_args a;
+    memset(&a, 0, sizeof(a));
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV;
+    a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = ldo;
+    a.ids = m->labels; a.ld_ids = m->L; a.pad_id = m->c.pad_id;
+    a.B = m->B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.mode = mode; a.drop_p = drop_p; a.drop_key = drop_key;
+    return bwd ? kzv_attn_bwd(&a, s) : kzv_attn_fwd(&a, s);
+}
+
+// ================================================================================================ forward
+int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss, float* d_logits, hipStream_t s) {
+    const kzv_config& c = m->c;
+    const int B = m->B, T = m->T, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
+    const int Me = B * m->Se, Mp = B * m->np, Md = B * T;
+    float* P = m->P;
+    const float eps = c.ln_eps;
+    m->labels = labels;
+    if (hipMemsetAsync(m->count, 0, 64 * sizeof(float), s) != hipSuccess) return kzv_fail(KZV_E_HIP, "forward: memset");
+    // ---- patch embedding: Conv2d(k=s=16) == im2row + GEMM (trocr_model.py:77,89-90) -----------------
+    KZV_TRY(kzv_im2row(px, m->patches, B, c.channels, c.image_h, c.image_w, c.patch_h, c.patch_w, s));
+    KZV_TRY(gemm(m->patches, m->PD, m->w_patch, false, Mp, He, m->PD, He, P + m->patch_b, m->pe32, He, KZV_EPI_F32, s));
+    float* x0 = m->Le ? m->ea[0].x_in : m->x_last;
+    KZV_TRY(kzv_embed_assemble(m->pe32, P + m->cls, P + m->pos, x0, B, m->np, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s));
+    // ---- ViT layers (pre-LN; HF modeling_vit.py:257-286) -----------------------------------------------
+    for (int i = 0; i < m->Le; ++i) {
+        EncAct& a = m->ea[i];
+        const EncLayerP& e = m->ep[i];
+        float* x_out = i + 1 < m->Le ? m->ea[i + 1].x_in : m->x_last;
+        KZV_TRY(kzv_ln_fwd_ex(a.x_in, P + e.ln1w, P + e.ln1b, a.ln1, nullptr, a.st1, Me, He, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm(a.ln1, He, m->w_eqkv[i], false, Me, 3 * He, He, 3 * He, P + e.qkvb, a.qkv, 3 * He, KZV_EPI_BF16, s));
+        KZV_TRY(attn(m, false, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, nullptr, nullptr, nullptr, nullptr,
+                     c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+        KZV_TRY(gemm(a.ctx, He, m->w_eo[i], false, Me, He, He, He, P + e.ob, a.x_mid, He, KZV_EPI_RESID, s, a.x_in, nullptr, 0,
+                     dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
+        KZV_TRY(kzv_ln_fwd_ex(a.x_mid, P + e.ln2w, P + e.ln2b, a.ln2, nullptr, a.st2, Me, He, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm(a.ln2, He, m->w_efc1[i], false, Me, Fe, He, Fe, P + e.fc1b, a.act, Fe, KZV_EPI_GELU, s, nullptr, a.pre, Fe));
+        KZV_TRY(gemm(a.act, Fe, m->w_efc2[i], false, Me, He, Fe, He, P + e.fc2b, x_out, He, KZV_EPI_RESID, s, a.x_mid, nullptr, 0,
+                     dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 2)));
+    }
+    // final LN, drop CLS (trocr_model.py:197-200), projection (:269)
+    KZV_TRY(kzv_ln_fwd_ex(m->x_last, P + m->lnf_w, P + m->lnf_b, m->enc_out, nullptr, m->stf, Me, He, eps, m->Se, 1, 0.f, 0, s));
+    if (m->has_proj)
+        KZV_TRY(gemm(m->enc_out, He, m->w_proj, false, Mp, Hd, He, Hd, P + m->proj_b, m->proj_out, Hd, KZV_EPI_BF16, s));
+    // cross-attention K/V of every decoder layer in one GEMM
+    const int CK = m->Ld * 2 * Hd;
+    KZV_TRY(gemm(m->proj_out, Hd, m->w_ckv, false, Mp, CK, Hd, CK, P + m->ckv_b, m->crosskv, CK, KZV_EPI_BF16, s));
+    // ---- decoder embeddings (HF modeling_roberta.py:75-122,142-155) --------------------------------------
+    KZV_TRY(kzv_dec_prepare(labels, B, m->L, c.pad_id, c.max_pos, m->posids, m->count, m->err, s));
+    KZV_TRY(kzv_embed_gather(labels, m->L, m->posids, P + m->word, P + m->dtype, P + m->dpos, m->emb_sum, B, T, Hd, s));
+    KZV_TRY(kzv_ln_fwd_ex(m->emb_sum, P + m->eln_w, P + m->eln_b, m->xd0h, m->xd0, m->emb_st, Md, Hd, eps, 1, 0,
+                          dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
+    // ---- decoder layers (post-LN; HF modeling_roberta.py:421-464) -------------------------------------------
+    const float* x = m->xd0; const bf16_t* xh = m->xd0h;
+    for (int i = 0; i < m->Ld; ++i) {
+        DecAct& a = m->da[i];
+        const DecLayerP& d = m->dp[i];
+        const uint32_t site = SITE_DEC_L + 8 * i;
+        KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, Md, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
+        KZV_TRY(attn(m, false, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, nullptr, nullptr, nullptr, nullptr,
+                     c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
+        KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, Md, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0,
+                     dp(m, c.dec_hidden_dropout), key(m, site + 1)));
+        KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, Md, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, Md, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
+        KZV_TRY(attn(m, false, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
+                     nullptr, nullptr, nullptr, nullptr, c.dec_heads, T, m->np, dp(m, c.dec_attn_dropout), key(m, site + 2), s));
+        KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, Md, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0,
+                     dp(m, c.dec_hidden_dropout), key(m, site + 3)));
+        KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, Md, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, Md, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
+        KZV_TRY(gemm(a.act, Fd, m->w_dfc2[i], false, Md, Hd, Fd, Hd, P + d.fc2b, a.s3, Hd, KZV_EPI_RESID, s, a.x2, nullptr, 0,
+                     dp(m, c.dec_hidden_dropout), key(m, site + 4)));
+        KZV_TRY(kzv_ln_fwd_ex(a.s3, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, Md, Hd, eps, 1, 0, 0.f, 0, s));
+        x = a.x3; xh = a.x3h;
+    }
+    // ---- LM head (HF modeling_roberta.py:877-893; decoder.weight tied to word embeddings :684-687) + CE --------
+    KZV_TRY(gemm(xh, Hd, m->w_hd, false, Md, Hd, Hd, Hd, P + m->hd_b, m->hd_gelu, Hd, KZV_EPI_GELU_F32, s, nullptr, m->hd_pre, Hd));
+    KZV_TRY(kzv_ln_fwd_ex(m->hd_gelu, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, Md, Hd, eps, 1, 0, 0.f, 0, s));
+    KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, Md, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
+    KZV_TRY(kzv_ce_fwd_bwd(m->logits, m->Vp, labels, m->L, B, T, m->V, c.pad_id, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, s));
+    if (d_loss && hipMemcpyAsync(d_loss, m->loss_acc, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return kzv_fail(KZV_E_HIP, "forward: loss copy");
+    if (d_logits) KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, Md, m->V, s));
+    return KZV_OK;
+}
+
+// ============================================================================================== backward
+// "dropout(linear(x)) + residual" backward helper: dy = mask(dx) (bf16) + bias grad, weight grad, input grad
+int lin_bwd_drop(const float* dx, bf16_t* dy, float* dbias, int M, int N, float drop_p, uint32_t drop_key, hipStream_t s) {
+    return kzv_cast_drop_colsum(dx, dy, dbias, M, N, drop_p, drop_key, s);
+}
+
+int backward_decoder(kzv_model* m, hipStream_t s) {
+    const kzv_config& c = m->c;
+    const int B = m->B, T = m->T, Hd = m->Hd, Fd = m->Fd, He = m->He;
+    const int Mp = B * m->np, Md = B * T, Me = B * m->Se;
+    float* P = m->P; float* G = m->G;
+    const int CK = m->Ld * 2 * Hd;
+    // ---- CE -> LM head ------------------------------------------------------------------------------
+    KZV_TRY(kzv_colsum_bf16(m->dlogits, m->Vp, G + m->hbias, Md, m->Vp, s));   // pad columns are 0; head.bias is padded to Vp
+    KZV_TRY(wgrad(m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, s));
+    KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
+    KZV_TRY(kzv_ln_bwd_ex(m->dhln, 0, m->hd_gelu, m->hd_st, P + m->hln_w, m->dsum_d, 0, G + m->hln_w, G + m->hln_b, Md, Hd, 1, 0, 0.f, 0, s));
+    KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
+    const bf16_t* x_last_h = m->Ld ? m->da[m->Ld - 1].x3h : m->xd0h;
+    KZV_TRY(wgrad(m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, s));
+    KZV_TRY(gemm(m->dy_d, Hd, m->w_hd, true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_F32, s));
+    // ---- decoder layers, last to first -----------------------------------------------------------------
+    for (int i = m->Ld - 1; i >= 0; --i) {
+        DecAct& a = m->da[i];
+        const DecLayerP& d = m->dp[i];
+        const uint32_t site = SITE_DEC_L + 8 * i;
+        const bf16_t* xh = i ? m->da[i - 1].x3h : m->xd0h;
+        // FFN block: x3 = LN(s3), s3 = x2 + drop(fc2(gelu(fc1(x2))))
+        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s3, a.st3, P + d.ln3w, m->dsum_d, 0, G + d.ln3w, G + d.ln3b, Md, Hd, 1, 0, 0.f, 0, s));
+        KZV_TRY(lin_bwd_drop(m->dsum_d, m->dy_d, G + d.fc2b, Md, Hd, dp(m, c.dec_hidden_dropout), key(m, site + 4), s));
+        KZV_TRY(wgrad(m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, s));
+        KZV_TRY(gemm(m->dy_d, Hd, m->w_dfc2[i], true, Md, Fd, Hd, Fd, nullptr, m->dbig_d, Fd, KZV_EPI_DGELU, s, nullptr, a.pre, Fd));
+        KZV_TRY(kzv_colsum_bf16(m->dbig_d, Fd, G + d.fc1b, Md, Fd, s));
+        KZV_TRY(wgrad(m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, s));
+        KZV_TRY(gemm(m->dbig_d, Fd, m->w_dfc1[i], true, Md, Hd, Fd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+        // cross-attention block: x2 = LN(s2), s2 = x1 + drop(o(CA(q(x1), kv(enc))))
+        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s2, a.st2, P + d.ln2w, m->dsum_d, 0, G + d.ln2w, G + d.ln2b, Md, Hd, 1, 0, 0.f, 0, s));
+        KZV_TRY(lin_bwd_drop(m->dsum_d, m->dy_d, G + d.cob, Md, Hd, dp(m, c.dec_hidden_dropout), key(m, site + 3), s));
+        KZV_TRY(wgrad(m->dy_d, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, s));
+        KZV_TRY(gemm(m->dy_d, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
+        KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
+                     m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->np,
+                     dp(m, c.dec_attn_dropout), key(m, site + 2), s));
+        KZV_TRY(kzv_colsum_bf16(m->dq_d, Hd, G + d.cqb, Md, Hd, s));
+        KZV_TRY(wgrad(m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, s));
+        KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+        // self-attention block: x1 = LN(s1), s1 = x + drop(o(SA(qkv(x))))
+        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s1, a.st1, P + d.ln1w, m->dsum_d, 0, G + d.ln1w, G + d.ln1b, Md, Hd, 1, 0, 0.f, 0, s));
+        KZV_TRY(lin_bwd_drop(m->dsum_d, m->dy_d, G + d.ob, Md, Hd, dp(m, c.dec_hidden_dropout), key(m, site + 1), s));
+        KZV_TRY(wgrad(m->dy_d, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, s));
+        KZV_TRY(gemm(m->dy_d, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
+        KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
+                     m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
+        KZV_TRY(kzv_colsum_bf16(m->dqkv_d, 3 * Hd, G + d.qkvb, Md, 3 * Hd, s));
+        KZV_TRY(wgrad(m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, s));
+        KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+    }
+    // ---- decoder embeddings: x0 = drop(LN(word + type + pos)) ---------------------------------------------
+    KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, m->emb_sum, m->emb_st, P + m->eln_w, m->dsum_d, 0, G + m->eln_w, G + m->eln_b, Md, Hd, 1, 0,
+                          dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
+    KZV_TRY(kzv_embed_scatter_bwd(m->dsum_d, m->labels, m->L, m->posids, G + m->word, G + m->dtype, G + m->dpos, B, T, Hd, c.pad_id, s));
+    // ---- cross K/V projection of all layers, encoder_decoder_proj, final encoder LN ---------------------------
+    KZV_TRY(kzv_colsum_bf16(m->dckv, CK, G + m->ckv_b, Mp, CK, s));
+    KZV_TRY(wgrad(m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, s));
+    KZV_TRY(gemm(m->dckv, CK, m->w_ckv, true, Mp, Hd, CK, Hd, nullptr, m->denc, Hd, KZV_EPI_BF16, s));
+    if (m->has_proj) {
+        KZV_TRY(kzv_colsum_bf16(m->denc, Hd, G + m->proj_b, Mp, Hd, s));
+        KZV_TRY(wgrad(m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, s));
+        KZV_TRY(gemm(m->denc, Hd, m->w_proj, true, Mp, He, Hd, He, nullptr, m->denc_out, He, KZV_EPI_BF16, s));
+    }
+    KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Se, 1, 0.f, 0, s));
+    return KZV_OK;
+}
+
+int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
+    const kzv_config& c = m->c;
+    const int He = m->He, Fe = m->Fe, Me = m->B * m->Se;
+    float* P = m->P; float* G = m->G;
+    EncAct& a = m->ea[i];
+    const EncLayerP& e = m->ep[i];
+    // x_out = x_mid + drop(fc2(gelu(fc1(LN2(x_mid)))))
+    KZV_TRY(lin_bwd_drop(m->dx_e, m->dy_e, G + e.fc2b, Me, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 2), s));
+    KZV_TRY(wgrad(m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, s));
+    KZV_TRY(gemm(m->dy_e, He, m->w_efc2[i], true, Me, Fe, He, Fe, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe));
+    KZV_TRY(kzv_colsum_bf16(m->dbig_e, Fe, G + e.fc1b, Me, Fe, s));
+    KZV_TRY(wgrad(m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, s));
+    KZV_TRY(gemm(m->dbig_e, Fe, m->w_efc1[i], true, Me, He, Fe, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s));
+    // x_mid = x_in + drop(o(attn(qkv(LN1(x_in)))))
+    KZV_TRY(lin_bwd_drop(m->dx_e, m->dy_e, G + e.ob, Me, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1), s));
+    KZV_TRY(wgrad(m->dy_e, He, a.ctx, He, G + e.ow, Me, He, He, He, s));
+    KZV_TRY(gemm(m->dy_e, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
+                 m->dqkv_e + 2 * He, c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+    KZV_TRY(kzv_colsum_bf16(m->dqkv_e, 3 * He, G + e.qkvb, Me, 3 * He, s));
+    KZV_TRY(wgrad(m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, s));
+    KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_in, a.st1, P + e.ln1w, m->dx_e, 1, G + e.ln1w, G + e.ln1b, Me, He, 1, 0, 0.f, 0, s));
+    return KZV_OK;
+}
+
+int backward_embed(kzv_model* m, hipStream_t s) {
+    const kzv_config& c = m->c;
+    const int He = m->He, Mp = m->B * m->np;
+    float* G = m->G;
+    KZV_TRY(kzv_embed_assemble_bwd(m->dx_e, m->dpatch, G + m->cls, G + m->pos, G + m->patch_b, m->B, m->np, He,
+                                   dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s));
+    KZV_TRY(wgrad(m->dpatch, He, m->patches, m->PD, G + m->patch_w, Mp, He, m->PD, He, s));
+    return KZV_OK;
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" int kzv_model_create(const kzv_config* cfg, kzv_model** out) {
+    if (!cfg || !out) return kzv_fail(KZV_E_ARG, "model_create: null");
+    const kzv_config& c = *cfg;
+    if (c.patch_h <= 0 || c.patch_w <= 0 || c.image_h % c.patch_h || c.image_w % c.patch_w)
+        return kzv_fail(KZV_E_ARG, "model_create: image %dx%d not divisible by patch %dx%d", c.image_h, c.image_w, c.patch_h, c.patch_w);
+    if (c.enc_heads <= 0 || c.dec_heads <= 0 || c.enc_hidden != 64 * c.enc_heads || c.dec_hidden != 64 * c.dec_heads)
+        return kzv_fail(KZV_E_ARG, "model_create: head_dim must be 64 (hidden = 64 * heads)");
+    if (c.enc_ffn % 64 || c.dec_ffn % 64 || (c.channels * c.patch_h * c.patch_w) % 64 || c.patch_w % 8)
+        return kzv_fail(KZV_E_ARG, "model_create: ffn sizes and C*ph*pw must be multiples of 64, patch_w of 8");
+    const int np = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
+    if (np + 1 > 192) return kzv_fail(KZV_E_ARG, "model_create: %d patches + CLS exceed the 192-token attention kernels", np);
+    if (c.vocab < 8 || c.max_pos < 4 || c.type_vocab < 1 || c.pad_id < 0 || c.pad_id >= c.vocab)
+        return kzv_fail(KZV_E_ARG, "model_create: bad vocabulary geometry");
+    if (c.enc_layers < 0 || c.dec_layers < 0) return kzv_fail(KZV_E_ARG, "model_create: negative layer count");
+    kzv_model* m = new kzv_model();
+    m->c = c;
+    m->np = np; m->Se = np + 1; m->PD = c.channels * c.patch_h * c.patch_w;
+    m->He = c.enc_hidden; m->Fe = c.enc_ffn; m->Hd = c.dec_hidden; m->Fd = c.dec_ffn;
+    m->V = c.vocab; m->Vp = (int)align_up(c.vocab, 64); m->Le = c.enc_layers; m->Ld = c.dec_layers;
+    m->has_proj = m->He != m->Hd;
+    build_param_table(m);
+    *out = m;
+    return KZV_OK;
+}
+
+extern "C" int kzv_model_destroy(kzv_model* m) { delete m; return KZV_OK; }
+extern "C" int kzv_param_count(const kzv_model* m) { return m ? (int)m->table.size() : 0; }
+extern "C" int64_t kzv_param_total(const kzv_model* m) { return m ? m->total : 0; }
+
+extern "C" int kzv_param_info(const kzv_model* m, int i, const char** name, int64_t* offset, int64_t* rows, int64_t* cols) {
+    if (!m || i < 0 || i >= (int)m->table.size()) return kzv_fail(KZV_E_ARG, "param_info: index out of range");
+    const PEntry& e = m->table[i];
+    if (name) *name = e.name.c_str();
+    if (offset) *offset = e.off;
+    if (rows) *rows = e.rows;
+    if (cols) *cols = e.cols;
+    return KZV_OK;
+}
+
+static int check_batch(const kzv_model* m, int batch, int label_len) {
+    if (batch <= 0) return kzv_fail(KZV_E_ARG, "batch must be positive");
+    if (label_len < 2) return kzv_fail(KZV_E_ARG, "labels need at least 2 columns");
+    if (label_len - 1 > 192) return kzv_fail(KZV_E_ARG, "decoder length %d exceeds the 192-token attention kernels", label_len - 1);
+    if ((int64_t)batch * m->Se * (int64_t)m->Fe >= (1ll << 31)) return kzv_fail(KZV_E_ARG, "batch too large for 32-bit element indices");
+    return KZV_OK;
+}
+
+extern "C" int64_t kzv_workspace_bytes(const kzv_model* m, int batch, int label_len) {
+    if (!m || check_batch(m, batch, label_len)) return -1;
+    kzv_model tmp = *m;   // plan() only writes pointer fields
+    tmp.P = nullptr;
+    return plan(&tmp, nullptr, batch, label_len);
+}
+
+extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, void* d_workspace, int64_t workspace_bytes,
+                              int batch, int label_len) {
+    if (!m || !d_params || !d_workspace) return kzv_fail(KZV_E_ARG, "model_bind: null");
+    KZV_TRY(check_batch(m, batch, label_len));
+    if (((uintptr_t)d_params | (uintptr_t)d_grads | (uintptr_t)d_workspace) & 255) return kzv_fail(KZV_E_ARG, "model_bind: buffers must be 256-byte aligned");
+    m->P = d_params; m->G = d_grads;
+    const int64_t need = plan(m, (char*)d_workspace, batch, label_len);
+    if (workspace_bytes < need) return kzv_fail(KZV_E_ARG, "model_bind: workspace %lld < required %lld", (long long)workspace_bytes, (long long)need);
+    m->ws = (char*)d_workspace; m->ws_bytes = workspace_bytes;
+    m->B = batch; m->L = label_len; m->T = label_len - 1;
+    if (!kzv_zero_page()) return kzv_fail(KZV_E_HIP, "model_bind: zero page");
+    // zero the bf16 weight region once (padding of transposed copies must read as 0), upload descriptors
+    const int64_t wbytes = (char*)m->d_desc - (char*)d_workspace;
+    if (hipMemset(d_workspace, 0, wbytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: memset");
+    if (hipMemcpy(m->d_desc, m->h_desc.data(), sizeof(KzvCastDesc) * m->ndesc, hipMemcpyHostToDevice) != hipSuccess)
+        return kzv_fail(KZV_E_HIP, "model_bind: descriptor upload");
+    m->bound = true; m->have_fwd = false;
+    return KZV_OK;
+}
+
+extern "C" int kzv_model_sync_weights(kzv_model* m, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "sync_weights: model not bound");
+    return kzv_cast_weights(m->d_desc, m->ndesc, m->cast_tiles, (hipStream_t)stream);
+}
+
+extern "C" int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels, float* d_loss,
+                                float* d_logits, int train, uint64_t seed, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "forward_loss: model not bound");
+    if (!d_pixel_values || !d_labels) return kzv_fail(KZV_E_ARG, "forward_loss: null input");
+    m->train = train != 0; m->seed = seed;
+    const int rc = forward(m, d_pixel_values, d_labels, d_loss, d_logits, (hipStream_t)stream);
+    m->have_fwd = rc == KZV_OK && m->train;
+    return rc;
+}
+
+extern "C" int kzv_zero_grads(kzv_model* m, void* stream) {
+    if (!m || !m->bound || !m->G) return kzv_fail(KZV_E_STATE, "zero_grads: no gradient buffer bound");
+    if (hipMemsetAsync(m->G, 0, m->total * sizeof(float), (hipStream_t)stream) != hipSuccess) return kzv_fail(KZV_E_HIP, "zero_grads");
+    return KZV_OK;
+}
+
+extern "C" int kzv_backward_segments(const kzv_model* m) { return m ? m->Le + 2 : 0; }
+
+extern "C" int kzv_backward_segment_range(const kzv_model* m, int seg, int64_t* lo, int64_t* hi) {
+    if (!m || seg < 0 || seg >= m->Le + 2) return kzv_fail(KZV_E_ARG, "segment_range: bad segment");
+    int64_t a, b;
+    if (seg == 0) { a = m->lnf_w; b = m->total; }                                   // decoder + proj + final LN
+    else if (seg <= m->Le) {                                                         // encoder layer Le - seg
+        const int i = m->Le - seg;
+        a = m->ep[i].ln1w; b = i + 1 < m->Le ? m->ep[i + 1].ln1w : m->lnf_w;
+    } else { a = 0; b = m->Le ? m->ep[0].ln1w : m->lnf_w; }                            // patch / cls / pos
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+    return KZV_OK;
+}
+
+extern "C" int kzv_backward_segment(kzv_model* m, int seg, void* stream) {
+    if (!m || !m->bound || !m->G) return kzv_fail(KZV_E_STATE, "backward: no gradient buffer bound");
+    if (!m->have_fwd) return kzv_fail(KZV_E_STATE, "backward: call kzv_forward_loss(train=1) first");
+    if (seg < 0 || seg >= m->Le + 2) return kzv_fail(KZV_E_ARG, "backward: bad segment");
+    hipStream_t s = (hipStream_t)stream;
+    if (seg == 0) return backward_decoder(m, s);
+    if (seg <= m->Le) return backward_enc_layer(m, m->Le - seg, s);
+    return backward_embed(m, s);
+}
+
+extern "C" int kzv_backward(kzv_model* m, void* stream) {
+    const int n = kzv_backward_segments(m);
+    for (int sgm = 0; sgm < n; ++sgm) KZV_TRY(kzv_backward_segment(m, sgm, stream));
+    return KZV_OK;
+}

@@ -1,0 +1,104 @@
+// Gradient clipping + RAdamScheduleFree step, fused over the flat fp32 buffers (HBM-bound:
+// reads p, z, v, g and writes p, z, v once = 28 B / parameter).
+// Replaces clip_grad_norm_(1.0) (scripts/train_trocr.py:175) and schedulefree.RAdamScheduleFree.step
+// (src/models/trocr_model.py:412-421).  The per-step scalars (lr_t, c_{k+1}, bias correction) are
+// computed on the host (kzv/optim.py) exactly as oracle/trocr_oracle.py::RAdamScheduleFreeState does.
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "kzv_kernels.h"
+
+namespace {
+
+constexpr int NORM_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ partial, int n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void clip_step_kernel(float* __restrict__ p, float* __restrict__ z, float* __restrict__ v,
+                                                        const float* __restrict__ g, int64_t n4,
+                                                        const float* __restrict__ sqnorm, const kzv_opt_step s) {
+    // total norm of the SCALED grads; torch: coef = clamp(max_norm / (norm + 1e-6), max=1)
+    float gs = s.grad_scale;
+    if (s.max_grad_norm > 0.f) {
+        const float norm = sqrtf(*sqnorm) * fabsf(s.grad_scale);
+        gs *= fminf(1.f, s.max_grad_norm / (norm + 1e-6f));
+    }
+    const float ylr = s.lr_t * (s.beta1 * (1.f - s.ckp1) - 1.f);
+    const float inv_bc2 = 1.f / s.bias_correction2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = ((float4*)p)[i], Z = ((float4*)z)[i], V = ((float4*)v)[i];
+        const float4 G4 = ((const float4*)g)[i];
+        float* pp = (float*)&P; float* zz = (float*)&Z; float* vv = (float*)&V; const float* gg = (const float*)&G4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gr = gg[r] * gs;
+            vv[r] = vv[r] * s.beta2 + (1.f - s.beta2) * gr * gr;
+            float gn = s.adaptive ? gr / (sqrtf(vv[r] * inv_bc2) + s.eps) : gr;
+            gn += s.weight_decay * pp[r];
+            float y = pp[r] + s.ckp1 * (zz[r] - pp[r]);
+            y += ylr * gn;
+            pp[r] = y;
+            zz[r] -= s.lr_t * gn;
+        }
+        ((float4*)p)[i] = P; ((float4*)z)[i] = Z; ((float4*)v)[i] = V;
+    }
+}
+
+__global__ __launch_bounds__(256) void lerp_kernel(float* __restrict__ p, const float* __restrict__ z, int64_t n4, float w) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = ((float4*)p)[i];
+        const float4 Z = ((const float4*)z)[i];
+        P.x += w * (Z.x - P.x); P.y += w * (Z.y - P.y); P.z += w * (Z.z - P.z); P.w += w * (Z.w - P.w);
+        ((float4*)p)[i] = P;
+    }
+}
+
+}  // namespace
+
+int kzv_sqnorm(const float* g, int64_t n, float* out1, float* scratch, hipStream_t s) {
+    if (n % 4) return kzv_fail(KZV_E_ARG, "sqnorm: n %% 4");
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, s, g, n / 4, scratch);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, NORM_BLOCKS, out1);
+    return kzv_check_launch("sqnorm");
+}
+
+extern "C" int kzv_grad_sqnorm(const float* d_grads, int64_t n, float* d_out1, float* d_scratch, void* stream) {
+    if (!d_grads || !d_out1 || !d_scratch) return kzv_fail(KZV_E_ARG, "grad_sqnorm: null");
+    return kzv_sqnorm(d_grads, n, d_out1, d_scratch, (hipStream_t)stream);
+}
+
+extern "C" int kzv_clip_and_step(float* d_params, float* d_z, float* d_v, const float* d_grads, int64_t n,
+                                 const float* d_sqnorm, const kzv_opt_step* s, void* stream) {
+    if (!d_params || !d_z || !d_v || !d_grads || !s) return kzv_fail(KZV_E_ARG, "clip_and_step: null");
+    if (n % 4) return kzv_fail(KZV_E_ARG, "clip_and_step: n %% 4");
+    if (s->max_grad_norm > 0.f && !d_sqnorm) return kzv_fail(KZV_E_ARG, "clip_and_step: clipping needs d_sqnorm");
+    hipLaunchKernelGGL(clip_step_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, d_params, d_z, d_v, d_grads, n / 4, d_sqnorm, *s);
+    return kzv_check_launch("clip_and_step");
+}
+
+extern "C" int kzv_lerp_params(float* d_params, const float* d_z, int64_t n, float w, void* stream) {
+    if (!d_params || !d_z || n % 4) return kzv_fail(KZV_E_ARG, "lerp_params: null or n %% 4");
+    hipLaunchKernelGGL(lerp_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, d_params, d_z, n / 4, w);
+    return kzv_check_launch("lerp_params");
+}

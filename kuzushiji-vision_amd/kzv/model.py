@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's ``TrOCRModel`` (src/models/trocr_model.py:205-460).
+
+Same constructor, same ``forward`` contract, same step / hook / utility methods, same ``state_dict`` key
+names -- but every FLOP runs in libkzv's hand-written HIP kernels through the C ABI of include/kzv.h.
+torch is used for device memory, streams and (in kzv.trainer) torch.distributed only; there is no
+autograd and no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import types
+from typing import Any
+
+from . import _lib as L
+from . import params as P
+from .config import ModelConfig, load_decoder_config
+
+
+class _Cfg(types.SimpleNamespace):
+    pass
+
+
+class TrOCRModel:
+    """TrOCR Model with ViT Encoder and RoBERTa Decoder (MI355X engine).
+
+    Mirrors src/models/trocr_model.py:208-217 (constructor), :258-321 (forward), :323-460 (steps, CER,
+    optimizer, mode hooks, decode_predictions).
+    """
+
+    def __init__(self, encoder_config: dict[str, Any], decoder_path: str, learning_rate: float = 1e-4,
+                 beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8, weight_decay: float = 0,
+                 *, device: str = "cuda", init_seed: int = 42, load_tokenizer: bool = True):
+        import torch
+        self.hparams = types.SimpleNamespace(encoder_config=encoder_config, decoder_path=decoder_path,
+                                             learning_rate=learning_rate, beta1=beta1, beta2=beta2,
+                                             epsilon=epsilon, weight_decay=weight_decay)
+        dec_cfg = load_decoder_config(decoder_path)          # FileNotFoundError like scripts/train_trocr.py:88-89
+        self.cfg = ModelConfig.from_reference(encoder_config, dec_cfg)
+        self.cfg.validate()
+        self.tokenizer = None
+        if load_tokenizer:
+            from transformers import AutoTokenizer                      # trocr_model.py:222
+            self.tokenizer = AutoTokenizer.from_pretrained(decoder_path)
+        # attribute surface used by scripts/test_trocr_setup.py:118-120
+        self.encoder = types.SimpleNamespace(config=_Cfg(hidden_size=self.cfg.enc_hidden), num_patches=self.cfg.num_patches)
+        self.decoder = types.SimpleNamespace(config=_Cfg(hidden_size=self.cfg.dec_hidden, vocab_size=self.cfg.vocab))
+        self.training = True
+        self.device = torch.device(device)
+        self.logged: dict[str, list[float]] = {}
+        self._optimizer = None
+        self._step_seed = 0
+
+        lib = L.load()
+        c = self.cfg
+        self._ccfg = L.kzv_config(
+            image_h=c.image_h, image_w=c.image_w, patch_h=c.patch_h, patch_w=c.patch_w, channels=c.channels,
+            enc_hidden=c.enc_hidden, enc_layers=c.enc_layers, enc_heads=c.enc_heads, enc_ffn=c.enc_ffn,
+            dec_hidden=c.dec_hidden, dec_layers=c.dec_layers, dec_heads=c.dec_heads, dec_ffn=c.dec_ffn,
+            vocab=c.vocab, max_pos=c.max_pos, type_vocab=c.type_vocab, pad_id=c.pad_id,
+            enc_hidden_dropout=c.enc_hidden_dropout, enc_attn_dropout=c.enc_attn_dropout,
+            dec_hidden_dropout=c.dec_hidden_dropout, dec_attn_dropout=c.dec_attn_dropout, ln_eps=c.ln_eps)
+        h = C.c_void_p()
+        L.check(lib.kzv_model_create(C.byref(self._ccfg), C.byref(h)), "kzv_model_create")
+        self._h = h
+        self._offsets, total = P.param_offsets(c)
+        if lib.kzv_param_total(h) != total:
+            raise L.KzvError("parameter table mismatch between kzv/params.py and libkzv")
+        self.flat_params = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._ws = None
+        self._bound = (0, 0)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # seeded init (the reference seeds 42: scripts/train_trocr.py:78); weights arrive via load_state_dict
+        self.flat_params.copy_(torch.from_numpy(P.recipe_flat(c, init_seed)))
+        # decoder weights from decoder_path if present (AutoModelForCausalLM.from_pretrained, trocr_model.py:231)
+        self._maybe_load_decoder_weights(decoder_path)
+
+    # ------------------------------------------------------------------ plumbing
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.load().kzv_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _maybe_load_decoder_weights(self, path: str) -> None:
+        f = os.path.join(path, "model.safetensors")
+        if not os.path.exists(f):
+            return
+        from safetensors.torch import load_file
+        sd = load_file(f)
+        mine = self.state_dict_views()
+        for k, v in sd.items():
+            name = "decoder." + k
+            if name in mine and tuple(mine[name].shape) == tuple(v.shape):
+                mine[name].copy_(v.to(self.device, dtype=mine[name].dtype))
+
+    def _bind(self, batch: int, label_len: int) -> None:
+        import torch
+        if self._bound == (batch, label_len):
+            return
+        lib = L.load()
+        need = lib.kzv_workspace_bytes(self._h, batch, label_len)
+        if need < 0:
+            L.check(-1, "kzv_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        L.check(lib.kzv_model_bind(self._h, self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
+                                   self._ws.data_ptr(), self._ws.numel(), batch, label_len), "kzv_model_bind")
+        self._bound = (batch, label_len)
+        self.sync_weights()
+
+    def sync_weights(self) -> None:
+        if self._bound != (0, 0):
+            L.check(L.load().kzv_model_sync_weights(self._h, L.stream_handle()), "sync_weights")
+
+    def zero_grad(self) -> None:
+        self.flat_grads.zero_()
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def state_dict_views(self):
+        """HF-named views into the flat master buffer (writing through them edits the model)."""
+        return P.state_dict_from_flat(self.cfg, self.flat_params)
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.state_dict_views().items()}
+
+    def grad_dict(self):
+        return {k: v for k, v in P.state_dict_from_flat(self.cfg, self.flat_grads).items()}
+
+    def load_state_dict(self, sd, strict: bool = True):
+        import torch
+        mine = self.state_dict_views()
+        seen = set()
+        for k, v in sd.items():
+            name = P.canonical_hf_name(k)
+            if name not in mine:
+                if strict:
+                    raise KeyError(f"unexpected key {k}")
+                continue
+            t = torch.as_tensor(v)
+            if tuple(t.shape) != tuple(mine[name].shape):
+                raise ValueError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(mine[name].shape)}")
+            mine[name].copy_(t.to(self.device, dtype=torch.float32))
+            seen.add(name)
+        if strict:
+            missing = [k for k in mine if k not in seen and k not in P.TIED_ALIASES]
+            if missing:
+                raise KeyError(f"missing keys: {missing[:4]}...")
+        self.sync_weights()
+        if self._optimizer is not None:
+            self._optimizer.z.copy_(self.flat_params)
+
+    def parameters(self):
+        return [self.flat_params]
+
+    def num_parameters(self) -> int:
+        return P.num_parameters(self.cfg)
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        return self
+
+    def log(self, name, value, **kw):
+        self.logged.setdefault(name, []).append(float(value))
+
+    def optimizers(self):
+        return self._optimizer
+
+    def __call__(self, pixel_values, labels=None):
+        return self.forward(pixel_values, labels)
+
+    # ------------------------------------------------------------------ forward (trocr_model.py:258-321)
+    def _check_inputs(self, pixel_values):
+        import torch
+        c = self.cfg
+        if pixel_values.dim() != 4 or pixel_values.shape[1] != c.channels:
+            raise ValueError(f"pixel_values must be [B,{c.channels},H,W], got {tuple(pixel_values.shape)}")
+        _, _, height, width = pixel_values.shape
+        if height != c.image_h or width != c.image_w:   # trocr_model.py:83-86
+            raise ValueError(f"Input image size ({height}*{width}) doesn't match model ({c.image_h}*{c.image_w}).")
+        return pixel_values.to(self.device, dtype=torch.float32).contiguous()
+
+    def forward_loss(self, pixel_values, labels, want_logits: bool = False, seed: int | None = None):
+        """Engine call: returns (loss tensor [1] on device, logits or None).  Dropout follows self.training."""
+        import torch
+        px = self._check_inputs(pixel_values)
+        lab = labels.to(self.device, dtype=torch.int64).contiguous()
+        if lab.dim() != 2 or lab.shape[0] != px.shape[0]:
+            raise ValueError("labels must be [B, L]")
+        B, Lh = lab.shape
+        self._bind(B, Lh)
+        logits = torch.empty(B, Lh - 1, self.cfg.vocab, dtype=torch.float32, device=self.device) if want_logits else None
+        if seed is None:
+            self._step_seed += 1
+            seed = self._step_seed
+        self._keep = (px, lab)   # inputs must outlive the asynchronous kernels (and backward reads labels)
+        L.check(L.load().kzv_forward_loss(self._h, px.data_ptr(), lab.data_ptr(), self._loss.data_ptr(), L.ptr(logits),
+                                          1 if self.training else 0, seed, L.stream_handle()), "kzv_forward_loss")
+        return self._loss, logits
+
+    def forward(self, pixel_values, labels=None):
+        if labels is not None:
+            loss, logits = self.forward_loss(pixel_values, labels, want_logits=True)
+            return {"logits": logits, "loss": loss.clone().reshape(())}
+        return {"generated_ids": self.generate(pixel_values), "logits": None}
+
+    def backward(self) -> None:
+        """loss.backward() of the last training-mode forward: fills flat_grads (zeroed first)."""
+        lib = L.load()
+        st = L.stream_handle()
+        L.check(lib.kzv_zero_grads(self._h, st), "zero_grads")
+        L.check(lib.kzv_backward(self._h, st), "kzv_backward")
+
+    def generate(self, pixel_values, max_length: int = 128):
+        """Greedy decode from BOS by repeated teacher-forced forwards (each position's logits only depend on
+        earlier ids under the causal mask).  The reference calls HF beam-4 ``generate`` (trocr_model.py:306-316);
+        beam search + KV cache is the N1 "next" row of SURVEY.md section 8(f) -- see DESIGN.md."""
+        import torch
+        c = self.cfg
+        px = self._check_inputs(pixel_values)
+        B = px.shape[0]
+        Lh = min(max_length, c.max_pos - c.pad_id - 1)
+        was = self.training
+        self.training = False
+        ids = torch.full((B, Lh), c.pad_id, dtype=torch.int64, device=self.device)
+        ids[:, 0] = c.bos_id
+        done = torch.zeros(B, dtype=torch.bool, device=self.device)
+        n = 1
+        for t in range(Lh - 1):
+            _, logits = self.forward_loss(px, ids, want_logits=True, seed=0)
+            nxt = logits[:, t].argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, c.pad_id), nxt)
+            ids[:, t + 1] = nxt
+            n = t + 2
+            done |= nxt == c.eos_id
+            if bool(done.all()):
+                break
+        self.training = was
+        return ids[:, :n]
+
+    # ------------------------------------------------------------------ Lightning-shaped steps (:323-398)
+    def training_step(self, batch, batch_idx):
+        loss, _ = self.forward_loss(batch["pixel_values"], batch["labels"], want_logits=False)
+        self.backward()
+        self.last_loss = loss
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        was = self.training
+        self.training = False
+        loss, _ = self.forward_loss(batch["pixel_values"], batch["labels"])
+        val = float(loss.item())
+        self.log("val_loss", val)
+        if batch_idx < 5 and self.tokenizer is not None:
+            gen = self.generate(batch["pixel_values"][:1])
+            pred = self.tokenizer.batch_decode(gen, skip_special_tokens=True)[0]
+            tgt = self.tokenizer.batch_decode(batch["labels"][:1], skip_special_tokens=True)[0]
+            self.log("val_cer", self.calculate_cer(pred, tgt))
+        self.training = was
+        return val
+
+    def test_step(self, batch, batch_idx):
+        was = self.training
+        self.training = False
+        loss, _ = self.forward_loss(batch["pixel_values"], batch["labels"])
+        val = float(loss.item())
+        self.log("test_loss", val)
+        if self.tokenizer is not None:
+            gen = self.generate(batch["pixel_values"])
+            preds = self.tokenizer.batch_decode(gen, skip_special_tokens=True)
+            tgts = self.tokenizer.batch_decode(batch["labels"], skip_special_tokens=True)
+            cers = [self.calculate_cer(p, t) for p, t in zip(preds, tgts)]
+            self.log("test_cer", sum(cers) / len(cers) if cers else 0.0)
+        self.training = was
+        return val
+
+    def calculate_cer(self, pred_text: str, target_text: str) -> float:
+        """Character Error Rate (trocr_model.py:400-410): Levenshtein / len(target)."""
+        if len(target_text) == 0:
+            return 1.0 if len(pred_text) > 0 else 0.0
+        return _levenshtein(pred_text, target_text) / len(target_text)
+
+    def configure_optimizers(self):
+        from .optim import RAdamScheduleFree
+        hp = self.hparams
+        self._optimizer = RAdamScheduleFree(self, lr=hp.learning_rate, betas=(hp.beta1, hp.beta2), eps=hp.epsilon,
+                                            weight_decay=hp.weight_decay)
+        return self._optimizer
+
+    # mode hooks (:423-451)
+    def on_train_epoch_start(self):
+        if self._optimizer is not None:
+            self._optimizer.train()
+
+    def on_validation_epoch_start(self):
+        if self._optimizer is not None:
+            self._optimizer.eval()
+
+    def on_validation_epoch_end(self):
+        if self._optimizer is not None:
+            self._optimizer.train()
+
+    def on_test_epoch_start(self):
+        if self._optimizer is not None:
+            self._optimizer.eval()
+
+    def on_predict_epoch_start(self):
+        if self._optimizer is not None:
+            self._optimizer.eval()
+
+    def decode_predictions(self, pixel_values) -> list[str]:
+        self.eval()
+        gen = self.generate(pixel_values)
+        return self.tokenizer.batch_decode(gen, skip_special_tokens=True)
+
+
+def _levenshtein(a: str, b: str) -> int:
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]

@@ -1,0 +1,163 @@
+"""Training runtime standing in for the pieces of ``pl.Trainer`` the reference uses on this path
+(scripts/train_trocr.py:165-176): one process per GPU, gradient all-reduce (mean) over RCCL overlapped with
+backward, ``gradient_clip_val=1.0`` applied AFTER the reduce on the identical full gradient, optimizer step,
+half-epoch validation, rank-0 logging/checkpoints.
+
+DDP semantics reproduced: each rank's loss is the mean over ITS non-pad tokens; gradients are
+summed across ranks and divided by world size; dropout streams differ per rank (seed mixes the rank).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+from . import _lib as L
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    return rank, world, local
+
+
+def init_distributed(backend: str | None = None):
+    """torch.distributed over RCCL ("nccl" on ROCm) for GPUs, gloo on CPU.  No-op for world size 1."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def bucket_plan(seg_ranges, bucket_elems: int):
+    """Merge consecutive backward segments (in completion order) into all-reduce buckets of at least
+    ``bucket_elems`` fp32 elements.  Returns [(last_segment_index, lo, hi)] -- a bucket is launched once its
+    last segment has been enqueued.  Ranges of merged segments are contiguous by construction of the
+    parameter table (decoder at the tail, encoder layers in descending order, embeddings at the head)."""
+    buckets = []
+    cur_lo = cur_hi = None
+    for i, (lo, hi) in enumerate(seg_ranges):
+        if cur_lo is None:
+            cur_lo, cur_hi = lo, hi
+        else:
+            if hi != cur_lo and lo != cur_hi:
+                raise ValueError("segments are not contiguous in completion order")
+            cur_lo, cur_hi = min(lo, cur_lo), max(hi, cur_hi)
+        if cur_hi - cur_lo >= bucket_elems or i == len(seg_ranges) - 1:
+            buckets.append((i, cur_lo, cur_hi))
+            cur_lo = cur_hi = None
+    return buckets
+
+
+class Stepper:
+    """One training step of the hot path: forward+loss, segmented backward with overlapped bucketed
+    all-reduce, clip, RAdamScheduleFree step, bf16 weight refresh."""
+
+    def __init__(self, model, optimizer, world: int = 1, max_grad_norm: float = 1.0, bucket_mb: float = 64.0):
+        self.model, self.opt, self.world, self.max_grad_norm = model, optimizer, world, max_grad_norm
+        lib = L.load()
+        n = lib.kzv_backward_segments(model._h)
+        self.seg_ranges = []
+        for s in range(n):
+            lo, hi = C.c_int64(), C.c_int64()
+            L.check(lib.kzv_backward_segment_range(model._h, s, C.byref(lo), C.byref(hi)), "segment_range")
+            self.seg_ranges.append((lo.value, hi.value))
+        # xGMI is point-to-point (7 links x ~153 GB/s): few large buckets keep every link busy and the launch
+        # count low; 64 MB fp32 buckets -> ~7 collectives per 393 MB gradient set.
+        self.buckets = bucket_plan(self.seg_ranges, int(bucket_mb * 1024 * 1024 / 4))
+
+    def step(self, batch, batch_idx: int = 0):
+        m, lib = self.model, L.load()
+        loss, _ = m.forward_loss(batch["pixel_values"], batch["labels"], want_logits=False)
+        st = L.stream_handle()
+        L.check(lib.kzv_zero_grads(m._h, st), "zero_grads")
+        works = []
+        if self.world > 1:
+            import torch.distributed as dist
+        bi = 0
+        for s in range(len(self.seg_ranges)):
+            L.check(lib.kzv_backward_segment(m._h, s, st), "backward_segment")
+            if self.world > 1 and s == self.buckets[bi][0]:
+                _, lo, hi = self.buckets[bi]
+                # async: RCCL waits for the kernels enqueued so far on this stream, then runs on its own
+                # stream while the remaining backward segments keep the compute stream busy
+                works.append(dist.all_reduce(m.flat_grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                bi += 1
+        for w in works:
+            w.wait()
+        self.opt.step(max_grad_norm=self.max_grad_norm, grad_scale=1.0 / self.world)
+        return loss
+
+
+def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: int = -1, log_every: int = 50,
+        val_check_interval: float = 0.5, ckpt_dir: str | None = None, world: int = 1, rank: int = 0, log=print):
+    """Minimal Trainer.fit: epochs over the loader, validation every ``val_check_interval`` of an epoch
+    (scripts/train_trocr.py:174), rank-0 checkpoints named like the reference (:138)."""
+    import torch
+    opt = model.configure_optimizers()
+    stepper = Stepper(model, opt, world=world)
+    gstep = 0
+    history = []
+    n_batches = len(train_loader)
+    val_every = max(1, int(n_batches * val_check_interval)) if val_loader is not None else 0
+    for epoch in range(max_epochs):
+        model.train()
+        model.on_train_epoch_start()
+        t0 = time.time()
+        for i, batch in enumerate(train_loader):
+            loss = stepper.step(batch, i)
+            gstep += 1
+            if gstep % log_every == 0 or gstep == 1:
+                lv = float(loss.item())
+                history.append((gstep, lv))
+                if rank == 0:
+                    log(f"epoch {epoch} step {gstep} train_loss {lv:.4f} lr {opt.scheduled_lr:.3g}")
+            if val_every and (i + 1) % val_every == 0:
+                model.on_validation_epoch_start()
+                vals = [model.validation_step(vb, j) for j, vb in enumerate(val_loader)]
+                model.on_validation_epoch_end()
+                model.train()
+                vl = sum(vals) / max(1, len(vals))
+                if rank == 0:
+                    log(f"epoch {epoch} step {gstep} val_loss {vl:.4f}")
+                    if ckpt_dir:
+                        os.makedirs(ckpt_dir, exist_ok=True)
+                        save_checkpoint(model, opt, os.path.join(ckpt_dir, f"trocr-epoch={epoch:02d}-val_loss={vl:.2f}.ckpt"), epoch, gstep)
+            if 0 < max_steps <= gstep:
+                break
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"epoch {epoch} done in {time.time() - t0:.1f}s")
+        if 0 < max_steps <= gstep:
+            break
+    if ckpt_dir and rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+        save_checkpoint(model, opt, os.path.join(ckpt_dir, "last.ckpt"), max_epochs - 1, gstep)
+    return history
+
+
+def save_checkpoint(model, opt, path: str, epoch: int, global_step: int) -> None:
+    """Lightning-shaped dict: state_dict under HF names + hyper-parameters + optimizer state."""
+    import torch
+    torch.save({"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
+                "hyper_parameters": vars(model.hparams), "optimizer_states": [opt.state_dict()]}, path)
+
+
+def load_checkpoint(model, opt, path: str):
+    import torch
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["state_dict"], strict=False)
+    if opt is not None and ck.get("optimizer_states"):
+        opt.load_state_dict(ck["optimizer_states"][0])
+    return ck

@@ -1,0 +1,163 @@
+"""Whole-path parity on the MI355X: kzv.TrOCRModel (HIP engine through the C ABI) vs
+  (1) the committed golden fixtures produced by the reference itself, and
+  (2) the CPU oracle on fresh seeded inputs.
+Stated tolerances: bf16 GEMM operands / fp32 accumulate -> logits within 3e-2 abs of
+the fp32 reference, identical argmax wherever the reference's own top-2 gap exceeds that tolerance,
+identical teacher-forced strings/CER on those positions, loss within 5e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from kzv import params as P
+from kzv.config import tiny_config, vit_b_config
+from kzv.data import build_decoder_dir, synthetic_batch
+from kzv.model import TrOCRModel
+from oracle import trocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 3e-2
+
+
+def _make(cfg, tmp_path, seed=42):
+    d = build_decoder_dir(str(tmp_path / f"dec{cfg.vocab}"), cfg)
+    m = TrOCRModel(cfg.encoder_config_dict(), d, init_seed=seed, load_tokenizer=False)
+    return m
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_tiny_matches_reference_fixture(tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_fwd_bwd.npz"))
+    cfg = tiny_config()
+    m = _make(cfg, tmp_path, int(g["seed"]))
+    m.eval()      # dropout off, as the fixture was generated
+    px = torch.from_numpy(g["pixel_values"])
+    lab = torch.from_numpy(g["labels"])
+    out = m(px, lab)
+    logits = out["logits"].cpu().numpy()
+    assert logits.shape == g["logits"].shape
+    assert np.abs(logits - g["logits"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - float(g["loss"])) < 5e-3
+    srt = np.sort(g["logits"], -1)
+    err = float(np.abs(logits - g["logits"]).max())
+    print(f"tiny: max|logit err|={err:.4g} loss err={abs(float(out['loss']) - float(g['loss'])):.3g}")
+    # argmax must agree wherever the reference's own top-2 gap exceeds twice the observed error bound
+    decided = (srt[..., -1] - srt[..., -2]) > 2 * err
+    assert decided.mean() > 0.8
+    assert np.array_equal(logits.argmax(-1)[decided], g["logits"].argmax(-1)[decided])
+    # gradients: train-mode forward with every dropout probability 0 == eval forward; run backward
+    m2 = _make(_no_dropout(cfg), tmp_path / "nd", int(g["seed"]))
+    m2.train()
+    loss, _ = m2.forward_loss(px, lab)
+    m2.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.item()) - float(g["loss"])) < 5e-3
+    grads = m2.grad_dict()
+    worst = {}
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        if name.startswith("decoder.lm_head.decoder."):
+            continue
+        got = grads[name].cpu().numpy()
+        want = g[k]
+        if name.endswith("key.bias"):
+            # true gradient is exactly 0 (softmax is invariant to a per-query shift); the reference holds
+            # fp32 noise ~1e-9 there, bf16 noise is ~1e-6: compare absolutely
+            assert np.abs(got).max() < 1e-4, name
+            continue
+        # bf16 operand rounding: relative to the tensor's largest entry
+        worst[name] = np.abs(got - want).max() / (np.abs(want).max() + 1e-9)
+    bad = {k: v for k, v in worst.items() if v > 0.05}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    assert np.median(list(worst.values())) < 0.02
+
+
+def _no_dropout(cfg):
+    import dataclasses
+    return dataclasses.replace(cfg, enc_hidden_dropout=0.0, enc_attn_dropout=0.0, dec_hidden_dropout=0.0, dec_attn_dropout=0.0)
+
+
+def test_tiny_fresh_inputs_match_oracle_and_batch_consistency(tmp_path):
+    cfg = tiny_config()
+    m = _make(cfg, tmp_path, 7)
+    m.eval()
+    px, lab = synthetic_batch(cfg, 5, 30, seed=3, min_chars=1, max_chars=29)
+    sd = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 7))
+    r = O.forward_backward(cfg, sd, px, lab)
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    logits = out["logits"].cpu().numpy()
+    assert np.abs(logits - r["logits"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - r["loss"]) < 5e-3
+    # reference test idiom (ocr_lightning/tests/test_model.py:48-76): singles == batched
+    one = m(torch.from_numpy(px[1:2]), torch.from_numpy(lab[1:2]))["logits"].cpu().numpy()
+    assert np.abs(one[0] - logits[1]).max() < 1e-3
+
+
+def test_vitb_summary_matches_reference_fixture(tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "vitb_b2_summary.npz"))
+    cfg = _no_dropout(vit_b_config())
+    m = _make(cfg, tmp_path, int(g["seed"]))
+    px, lab = synthetic_batch(cfg, int(g["batch"]), int(g["label_len"]), seed=int(g["data_seed"]), min_chars=3,
+                              max_chars=int(g["label_len"]))
+    m.train()
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    logits = out["logits"].cpu().numpy()
+    idx = g["logit_idx"]
+    assert np.abs(logits[idx[:, 0], idx[:, 1], idx[:, 2]] - g["logit_val"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - float(g["loss"])) < 5e-3
+    err = float(np.abs(logits[idx[:, 0], idx[:, 1], idx[:, 2]] - g["logit_val"]).max())
+    print(f"vit-b: max|logit err| (4096 samples)={err:.4g} loss err={abs(float(out['loss']) - float(g['loss'])):.3g}")
+    decided = g["top2_gap"] > 4 * err
+    agree = logits.argmax(-1) == g["argmax"]
+    print(f"vit-b: argmax agreement {agree.mean():.4f}, decided fraction {decided.mean():.3f}")
+    assert agree[decided].all()
+    assert agree.mean() > 0.9
+    m.backward()
+    torch.cuda.synchronize()
+    grads = m.grad_dict()
+    norms = dict(zip([str(s) for s in g["grad_names"]], g["grad_norms"]))
+    bad = {}
+    for name, want in norms.items():
+        if name.startswith("decoder.lm_head.decoder."):
+            continue
+        got = float(grads[name].double().norm().item())
+        if abs(got - want) > 0.03 * want + 2e-5:   # key biases have an exactly-zero true gradient (softmax shift invariance)
+            bad[name] = (got, want)
+    assert not bad, list(bad.items())[:8]
+
+
+def test_image_size_mismatch_raises_like_reference(tmp_path):
+    m = _make(tiny_config(), tmp_path)
+    with pytest.raises(ValueError, match="doesn't match model"):
+        m(torch.zeros(1, 3, 32, 48), torch.ones(1, 8, dtype=torch.int64))
+
+
+def test_training_step_with_dropout_reduces_loss(tmp_path):
+    """A few real optimizer steps (dropout ON, clip 1.0, RAdamScheduleFree) on one batch must lower the loss."""
+    cfg = tiny_config()
+    m = _make(cfg, tmp_path, 3)
+    opt = m.configure_optimizers()
+    opt.lr = 3e-3
+    px, lab = synthetic_batch(cfg, 8, 24, seed=11, min_chars=4, max_chars=23)
+    batch = {"pixel_values": torch.from_numpy(px), "labels": torch.from_numpy(lab)}
+    m.train()
+    losses = []
+    for i in range(60):
+        loss = m.training_step(batch, i)
+        opt.step(max_grad_norm=1.0)
+        losses.append(float(loss.item()))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.5, (losses[:5], losses[-5:])
+    # eval-mode swap (x average) keeps a finite, comparable loss and swaps back exactly-ish
+    before = m.flat_params.clone()
+    opt.eval()
+    v = m.validation_step(batch, 99)
+    opt.train()
+    assert np.isfinite(v)
+    assert (m.flat_params - before).abs().max().item() < 1e-5
