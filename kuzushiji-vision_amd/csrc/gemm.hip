@@ -17,12 +17,13 @@
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
-constexpr int NT_LDS = 2 * STAGE_BYTES;           // 64 KiB -> 2 workgroups / CU
+constexpr int BK = 64;
+constexpr int STAGE_BYTES = (128 + 128) * BK * 2;   // gemm_tn stage: 32 KiB
+constexpr int NT_LDS = 2 * STAGE_BYTES;             // gemm_tn: 64 KiB -> 2 workgroups / CU
 
 struct NtParams {
     const bf16_t* A; const bf16_t* B; void* C; const float* bias; const float* resid; bf16_t* aux;
@@ -32,40 +33,60 @@ struct NtParams {
     unsigned drop_thr16; float drop_inv_keep; unsigned drop_key;
 };
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// Workgroup = WM x WN waves, each wave a 64x64 output tile (4x4 MFMA 16x16x32 tiles); block tile
+// BM = 64*WM rows by BN = 64*WN columns; NSTAGE-deep LDS ring of [BM + BN][64] bf16 stages filled by
+// LDS-DMA.  NSTAGE-2 stages stay in flight ACROSS the per-step barrier (counted vmcnt + raw s_barrier).
+template <int EPI, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p) {
+    constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
+    constexpr int STAGE = (BM + BN) * BK * 2;
+    constexpr int PPW = (BM + BN) / 8 / NW;          // 1-KiB LDS-DMA pieces per wave per stage
+    static_assert((BM + BN) / 8 % NW == 0, "pieces must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w - wm * WN;
     const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, tilesM * tilesN);
     const int tm = id / tilesN, tn = id - tm * tilesN;
 
-    // ---- per-lane source pointers for the 4+4 LDS-DMA pieces this wave issues per stage ----
-    // piece j covers tile rows w*32 + j*8 .. +7 (8 rows x 128 B); lane -> row lane>>3, 16-B slot lane&7.
-    // slot s of row r holds source chunk s ^ (r & 7)   (involution; the read applies the same XOR)
-    const char* pa[4]; const char* pb[4]; int sa[4], sb[4];
+    // ---- per-lane source pointers for the LDS-DMA pieces this wave issues per stage ----
+    // piece pc covers stage rows pc*8 .. +7 (8 rows x 128 B; rows < BM belong to A, the rest to B);
+    // lane -> row lane>>3, 16-B slot lane&7; slot s of row r holds source chunk s ^ (r & 7)
+    // (involution; the fragment read applies the same XOR).
+    const char* src[PPW]; int inc[PPW];
     {
         const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = w * 32 + j * 8 + r8;
-            const int am = tm * BM + row, bn = tn * BN + row;
-            const bool va = am < p.M, vb = bn < p.n_valid;
-            pa[j] = va ? (const char*)(p.A + (int64_t)am * p.lda + chunk * 8) : (const char*)p.zero16;
-            pb[j] = vb ? (const char*)(p.B + (int64_t)bn * p.ldb + chunk * 8) : (const char*)p.zero16;
-            sa[j] = va ? BK * 2 : 0;
-            sb[j] = vb ? BK * 2 : 0;
+        for (int j = 0; j < PPW; ++j) {
+            const int row = (w + j * NW) * 8 + r8;
+            if (row < BM) {
+                const int am = tm * BM + row;
+                const bool v = am < p.M;
+                src[j] = v ? (const char*)(p.A + (int64_t)am * p.lda + chunk * 8) : (const char*)p.zero16;
+                inc[j] = v ? BK * 2 : 0;
+            } else {
+                const int bn = tn * BN + row - BM;
+                const bool v = bn < p.n_valid;
+                src[j] = v ? (const char*)(p.B + (int64_t)bn * p.ldb + chunk * 8) : (const char*)p.zero16;
+                inc[j] = v ? BK * 2 : 0;
+            }
         }
     }
     auto stage = [&](int s) {
-        char* dA = smem + s * STAGE_BYTES + (w * 32) * 128;
-        char* dB = dA + BM * BK * 2;
+        char* d = smem + s * STAGE + w * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { glds16(pa[j], dA + j * 1024); pa[j] += sa[j]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { glds16(pb[j], dB + j * 1024); pb[j] += sb[j]; }
+        for (int j = 0; j < PPW; ++j) { glds16(src[j], d + j * NW * 1024); src[j] += inc[j]; }
     };
 
     f32x4 acc[4][4];
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     const int sw = lane & 7;
 
     auto compute = [&](int s) {
-        const char* base = smem + s * STAGE_BYTES;
+        const char* base = smem + s * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = ((ks * 4 + g) ^ sw) << 4;
@@ -97,19 +118,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         }
     };
 
+    // ring schedule: stages t+1 .. t+NSTAGE-2 are in flight while stage t is consumed.  The barrier at the
+    // top of step t (a) publishes every wave's stage-t pieces (each wave waited for its own) and (b) proves
+    // every wave finished reading buffer (t-1)%NSTAGE, which stage t+NSTAGE-1 then overwrites.
     const int nk = p.K / BK;
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nk - 1; ++t) {
-        stage(cur ^ 1);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) stage(s);
+    int buf = 0, nxt = NSTAGE - 1;
+    for (int t = 0; t < nk; ++t) {
+        if (t + NSTAGE - 2 < nk) wait_vmcnt<PPW * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NSTAGE - 1 < nk) stage(nxt);
+        compute(buf);
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
-    compute(cur);
 
     // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row i*16 + l15, n0 = j*16 + 4g ----
 #pragma unroll
@@ -208,18 +233,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool in = t0 + rowj[j] < t_end;
-            glds16((in && pp[j]) ? pp[j] : (const char*)p.zero16, dP + j * 1024);
+            glds16_asm((in && pp[j]) ? pp[j] : (const char*)p.zero16, dP + j * 1024);
             if (pp[j]) pp[j] += sp[j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool in = t0 + rowj[j] < t_end;
-            glds16((in && pq[j]) ? pq[j] : (const char*)p.zero16, dQ + j * 1024);
+            glds16_asm((in && pq[j]) ? pq[j] : (const char*)p.zero16, dQ + j * 1024);
             if (pq[j]) pq[j] += sq[j];
         }
     };
 
-    f32x4 acc[4][4];   // [k-tile][n-tile]: D rows = k (4g+r), D cols = n (l15)
+    f32x4 acc[4][4];   // [k-tile i][n-tile j]: D rows = n (4g+r), D cols = k (l15)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -257,47 +282,55 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[i], fp[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[j], fq[i], acc[i][j], 0, 0, 0);
         }
     };
 
     const int nt = (t_end - t_begin + 63) / 64;
     stage(0, t_begin);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     int cur = 0;
-    for (int t = 0; t < nt - 1; ++t) {
-        stage(cur ^ 1, t_begin + (t + 1) * 64);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage t have landed
+        __builtin_amdgcn_s_barrier();                        // ... and everybody's; buffer cur^1 is free again
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) stage(cur ^ 1, t_begin + (t + 1) * 64);
         compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         cur ^= 1;
     }
-    compute(cur);
 
-    // lane holds OUT[n][k0..k0+3], n = tnb*128 + wn*64 + j*16 + l15, k0 = tkb*128 + wk*64 + i*16 + 4g
+    // ---- epilogue: accumulators -> LDS (fp32 [128 n][128 k], 16-B chunks XOR-swizzled by row) -> each
+    // wave-instruction adds ONE 256-byte row segment (64 consecutive k) to OUT: the shape global float
+    // atomics run at full rate with (MI355X_MICROARCH.md, Global float atomics).
+    __syncthreads();                                   // every wave is done reading the operand stages
+    float* tile = (float*)smem;                        // 128 * 128 * 4 B = 64 KiB = the whole ring
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = tnb * 128 + wn * 64 + j * 16 + l15;
-        if (n >= p.n_store) continue;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k0 = tkb * 128 + wk * 64 + i * 16 + 4 * g;
-            if (k0 >= p.K) continue;
-            float* o = p.OUT + (int64_t)n * p.ldo + k0;
-            if (p.splits == 1) {
-                float4 c = *(float4*)o;
-                c.x += acc[i][j][0]; c.y += acc[i][j][1]; c.z += acc[i][j][2]; c.w += acc[i][j][3];
-                *(float4*)o = c;
-            } else {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(o + r, acc[i][j][r]);
+            for (int r = 0; r < 4; ++r) {
+                const int n = wn * 64 + j * 16 + 4 * g + r, k = wk * 64 + i * 16 + l15;
+                tile[n * 128 + ((((k >> 2) ^ (n & 31)) << 2) | (k & 3))] = acc[i][j][r];
             }
+    __syncthreads();
+    for (int it = 0; it < 64; ++it) {
+        const int n = w * 32 + (it >> 1), k = (it & 1) * 64 + lane;
+        const int gn = tnb * 128 + n, gk = tkb * 128 + k;
+        if (gn < p.n_store && gk < p.K) {
+            const float v = tile[n * 128 + ((((k >> 2) ^ (n & 31)) << 2) | (k & 3))];
+            float* o = p.OUT + (int64_t)gn * p.ldo + gk;
+            if (p.splits == 1) *o += v; else atomicAdd(o, v);
         }
     }
 }
 
 }  // namespace
+
+static int kzv_nt_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("KZV_NT_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
 
 extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return kzv_fail(KZV_E_ARG, "gemm_nt: null operand");
@@ -316,25 +349,32 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.M = a->M; p.N = a->N; p.K = a->K; p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
     kzv_drop_params(a->drop_p, &p.drop_thr16, &p.drop_inv_keep);
     p.drop_key = a->drop_key;
-    const int grid = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
-#define KZV_NT_LAUNCH(E)                                                                                  \
+#define KZV_NT_CASE(E, WM, WN, NS)                                                                        \
     case E: {                                                                                             \
+        constexpr int lds = NS * (WM + WN) * 64 * BK * 2;                                                 \
         static bool attr_done = false;                                                                    \
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS); attr_done = true; } \
-        hipLaunchKernelGGL(gemm_nt_kernel<E>, dim3(grid), dim3(256), NT_LDS, s, p);                       \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
+        const int grid = ((a->M + WM * 64 - 1) / (WM * 64)) * ((a->N + WN * 64 - 1) / (WN * 64));         \
+        hipLaunchKernelGGL((gemm_nt_kernel<E, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);   \
     } break;
-    switch (epilogue) {
-        KZV_NT_LAUNCH(KZV_EPI_BF16)
-        KZV_NT_LAUNCH(KZV_EPI_F32)
-        KZV_NT_LAUNCH(KZV_EPI_GELU)
-        KZV_NT_LAUNCH(KZV_EPI_RESID)
-        KZV_NT_LAUNCH(KZV_EPI_DGELU)
-        KZV_NT_LAUNCH(KZV_EPI_GELU_F32)
-        default: return kzv_fail(KZV_E_ARG, "gemm_nt: unknown epilogue");
+#define KZV_NT_VARIANT(WM, WN, NS)                                                                        \
+    switch (epilogue) {                                                                                   \
+        KZV_NT_CASE(KZV_EPI_BF16, WM, WN, NS) KZV_NT_CASE(KZV_EPI_F32, WM, WN, NS)                        \
+        KZV_NT_CASE(KZV_EPI_GELU, WM, WN, NS) KZV_NT_CASE(KZV_EPI_RESID, WM, WN, NS)                      \
+        KZV_NT_CASE(KZV_EPI_DGELU, WM, WN, NS) KZV_NT_CASE(KZV_EPI_GELU_F32, WM, WN, NS)                  \
+        default: return kzv_fail(KZV_E_ARG, "gemm_nt: unknown epilogue");                                 \
     }
-#undef KZV_NT_LAUNCH
+    switch (kzv_nt_variant()) {
+        case 1: KZV_NT_VARIANT(2, 2, 3) break;
+        case 2: KZV_NT_VARIANT(4, 2, 2) break;
+        case 3: KZV_NT_VARIANT(4, 2, 3) break;
+        case 4: KZV_NT_VARIANT(2, 4, 3) break;
+        default: KZV_NT_VARIANT(2, 2, 2) break;
+    }
+#undef KZV_NT_VARIANT
+#undef KZV_NT_CASE
     return kzv_check_launch("gemm_nt");
 }
 
@@ -350,7 +390,14 @@ extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
     p.Mtok = a->Mtok; p.N = a->N; p.K = a->K; p.n_store = a->n_store > 0 ? a->n_store : a->N;
     const int tiles = ((a->N + 127) / 128) * ((a->K + 127) / 128);
     const int tok_tiles = (a->Mtok + 63) / 64;
-    int splits = (768 + tiles - 1) / tiles;            // aim for ~3 workgroups per CU
+    // Token splits: fill the 512 resident slots (256 CUs x 2 workgroups) in ONE round without overshooting
+    // it, and keep >= 16 reduction steps per workgroup so the 64 float atomics per lane of the epilogue
+    // (issue-bound, and contended when many splits hit one small output) stay a small share.
+    static int target = -1, min_steps = -1;
+    if (target < 0) { const char* e = getenv("KZV_TN_BLOCKS"); target = e ? atoi(e) : 512; }
+    if (min_steps < 0) { const char* e = getenv("KZV_TN_MINSTEPS"); min_steps = e ? atoi(e) : 16; }
+    int splits = target / tiles;
+    if (splits > tok_tiles / min_steps) splits = tok_tiles / min_steps;
     if (splits > tok_tiles) splits = tok_tiles;
     if (splits < 1) splits = 1;
     int chunk_tiles = (tok_tiles + splits - 1) / splits;

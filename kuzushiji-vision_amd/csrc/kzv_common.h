@@ -70,6 +70,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const KZV_GLB void*)g, (KZV_LDS void*)lds_wave_base, 16, 0, 0);
 }
+// Same LDS-DMA issued from inline asm: invisible to hipcc's waitcnt pass, so the compiler does not put a
+// vmcnt(0) in front of later LDS reads it cannot disambiguate (it does for ds_read_b64_tr_b16 after a
+// builtin LDS-DMA, which serialises load and compute).  The CALLER owns the wait: s_waitcnt vmcnt(N), then
+// a barrier, before any wave reads the bytes.  lds_dst must be wave-uniform (it is moved into M0).
+__device__ __forceinline__ void glds16_asm(const void* g, void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
 __device__ __forceinline__ bf16x4 lds_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((KZV_LDS bf16x4*)p);
 }
