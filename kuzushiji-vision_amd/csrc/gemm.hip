@@ -136,20 +136,50 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
 
-    // ---- epilogue: lane holds C[m][n0..n0+3], m = tile row i*16 + l15, n0 = j*16 + 4g ----
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    // Accumulators (lane: C[m = i*16 + l15][n0 = j*16 + 4g .. +3]) go through LDS (the ring is free now) so
+    // that global traffic is row-contiguous: one thread = 4 consecutive columns, 32 threads = one 128-column
+    // row (256 B of bf16 / 512 B of fp32 per row per instruction, residual/aux loads included).
+    static_assert(NSTAGE * STAGE >= BM * BN * 4, "LDS ring too small to stage the fp32 tile");
+    __syncthreads();
+    float* tile = (float*)smem;                       // [BM][BN] fp32, 16-B chunks XOR-swizzled by (row & 31)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = tm * BM + wm * 64 + i * 16 + l15;
-        if (m >= p.M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n0 = tn * BN + wn * 64 + j * 16 + 4 * g;
-            if (n0 >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (EPI != KZV_EPI_DGELU && p.bias) {
+            const int ml = wm * 64 + i * 16 + l15, c = wn * 16 + j * 4 + g;
+            *(f32x4*)(tile + ml * BN + ((c ^ (ml & 31)) << 2)) = acc[i][j];
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 4, RSTEP = NW * 64 / CPR;
+    const int c = tid % CPR;
+    const int n0 = tn * BN + c * 4;
+    if (n0 >= p.N) return;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI != KZV_EPI_DGELU && p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (n0 + r < p.n_valid) ? p.bias[n0 + r] : 0.f;
-            }
+        for (int r = 0; r < 4; ++r) b4[r] = (n0 + r < p.n_valid) ? p.bias[n0 + r] : 0.f;
+    }
+    // rows are processed 8 at a time with the residual / aux loads of the batch issued up front, so the
+    // per-row global-load latency overlaps instead of serialising 16 dependent round trips per tile
+    constexpr int NP = BM / RSTEP;
+    static_assert(NP % 8 == 0, "row passes come in batches of 8");
+#pragma unroll
+    for (int pb = 0; pb < NP; pb += 8) {
+        float4 r4[8]; uint2 u2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int m = tm * BM + tid / CPR + (pb + q) * RSTEP;
+            if (EPI == KZV_EPI_RESID) r4[q] = m < p.M ? *(const float4*)(p.resid + (int64_t)m * p.ldr + n0) : make_float4(0, 0, 0, 0);
+            if (EPI == KZV_EPI_DGELU) u2[q] = m < p.M ? *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rr = tid / CPR + (pb + q) * RSTEP;
+            const int m = tm * BM + rr;
+            if (m >= p.M) continue;
+            const f32x4 a4 = *(const f32x4*)(tile + rr * BN + ((c ^ (rr & 31)) << 2));
+            float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
             if (EPI == KZV_EPI_BF16) {
                 *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             } else if (EPI == KZV_EPI_F32) {
@@ -170,15 +200,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
                     v[2] *= drop_keep(b1, 0, p.drop_thr16, p.drop_inv_keep);
                     v[3] *= drop_keep(b1, 1, p.drop_thr16, p.drop_inv_keep);
                 }
-                const float4 r4 = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
                 *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) =
-                    make_float4(v[0] + r4.x, v[1] + r4.y, v[2] + r4.z, v[3] + r4.w);
+                    make_float4(v[0] + r4[q].x, v[1] + r4[q].y, v[2] + r4[q].z, v[3] + r4[q].w);
             } else if (EPI == KZV_EPI_DGELU) {
-                const uint2 u = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
-                v[0] *= gelu_erf_grad(bf2f((bf16_t)(u.x & 0xffff)));
-                v[1] *= gelu_erf_grad(bf2f((bf16_t)(u.x >> 16)));
-                v[2] *= gelu_erf_grad(bf2f((bf16_t)(u.y & 0xffff)));
-                v[3] *= gelu_erf_grad(bf2f((bf16_t)(u.y >> 16)));
+                v[0] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].x & 0xffff)));
+                v[1] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].x >> 16)));
+                v[2] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].y & 0xffff)));
+                v[3] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].y >> 16)));
                 *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
             }
         }
@@ -366,13 +394,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
         KZV_NT_CASE(KZV_EPI_DGELU, WM, WN, NS) KZV_NT_CASE(KZV_EPI_GELU_F32, WM, WN, NS)                  \
         default: return kzv_fail(KZV_E_ARG, "gemm_nt: unknown epilogue");                                 \
     }
-    switch (kzv_nt_variant()) {
-        case 1: KZV_NT_VARIANT(2, 2, 3) break;
-        case 2: KZV_NT_VARIANT(4, 2, 2) break;
-        case 3: KZV_NT_VARIANT(4, 2, 3) break;
-        case 4: KZV_NT_VARIANT(2, 4, 3) break;
-        default: KZV_NT_VARIANT(2, 2, 2) break;
-    }
+    KZV_NT_VARIANT(2, 2, 2)
 #undef KZV_NT_VARIANT
 #undef KZV_NT_CASE
     return kzv_check_launch("gemm_nt");

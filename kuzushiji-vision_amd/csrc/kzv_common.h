@@ -51,11 +51,30 @@ __device__ __forceinline__ float drop_keep(unsigned bits, int which, unsigned th
     return r >= thr16 ? inv_keep : 0.f;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf-GELU and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7 before fp32 rounding):
+// one v_rcp, one v_exp and 6 FMAs instead of libm's erff (~60 VALU ops), which made the GEMM epilogues
+// VALU-bound.  The Gaussian the derivative needs is the same exponential (exp(-(x/sqrt2)^2) = exp(-x^2/2)).
+__device__ __forceinline__ void kzv_erf_parts(float x, float* erf_out, float* gauss_out) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    const float e = __expf(-z * z);
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float er = fmaf(-poly * t, e, 1.f);
+    *erf_out = copysignf(er, x);
+    *gauss_out = e;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float er, e;
+    kzv_erf_parts(x, &er, &e);
+    return 0.5f * x * (1.f + er);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float er, e;
+    kzv_erf_parts(x, &er, &e);
+    return fmaf(x * 0.39894228040143268f, e, 0.5f * (1.f + er));
 }
 
 // XCD-aware block remap (bijective for any grid size): blocks that share an XCD under round-robin
