@@ -98,3 +98,102 @@ class SyntheticLineDataset:
         text = "".join(self._chars[t - 5] for t in lab[0] if t != self.cfg.pad_id)
         return {"pixel_values": torch.from_numpy(px[0]), "labels": torch.from_numpy(lab[0]),
                 "text": text, "image_path": f"synthetic://{i}"}
+
+
+# ---- real-data plumbing (src/data/trocr_dataset.py) ---------------------------------------------------------
+def resize_with_padding(image, target_size, fill_color=(255, 255, 255)):
+    """ResizeWithPadding.__call__ (src/data/trocr_dataset.py:24-53): scale = min(w-ratio, h-ratio), int()
+    truncation, LANCZOS, paste centred on a white canvas.  image: PIL.Image; target_size = (H, W)."""
+    from PIL import Image
+    th, tw = target_size
+    ow, oh = image.size
+    scale = min(tw / ow, th / oh)
+    nw, nh = int(ow * scale), int(oh * scale)
+    image = image.resize((nw, nh), Image.Resampling.LANCZOS)
+    canvas = Image.new("RGB", (tw, th), fill_color)
+    canvas.paste(image, ((tw - nw) // 2, (th - nh) // 2))
+    return canvas
+
+
+def image_to_tensor(image):
+    """ToTensor + Normalize(0.5, 0.5) (trocr_dataset.py:101-102): uint8 HWC -> fp32 CHW in [-1, 1]."""
+    import torch
+    a = np.asarray(image, dtype=np.float32) / 255.0
+    return torch.from_numpy(((a - 0.5) / 0.5).transpose(2, 0, 1).copy())
+
+
+class LineCsvDataset:
+    """TrOCRDataset (src/data/trocr_dataset.py:56-201): column_info.csv rows -> {"pixel_values","labels","text",
+    "image_path"}; deterministic 42-seeded shuffle, then train/val/test slices; unreadable images become zeros."""
+
+    def __init__(self, csv_path, image_root, tokenizer, image_size=(1024, 64), max_length=128, split="train",
+                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1):
+        import ast
+        import pandas as pd
+        if abs(train_ratio + val_ratio + test_ratio - 1.0) >= 1e-6:
+            raise AssertionError("Ratios must sum to 1.0")
+        self.image_root, self.image_size, self.max_length, self.tokenizer = image_root, tuple(image_size), max_length, tokenizer
+        df = pd.read_csv(csv_path).dropna()
+        df["unicode_ids"] = df["unicode_ids"].apply(ast.literal_eval)
+        df["text"] = df["unicode_ids"].apply(self._ids_to_text)
+        df = df[df["text"].str.len() > 0]
+        df = df.reset_index(drop=True)          # the reference slices in file order (trocr_dataset.py:153-171)
+        n = len(df)
+        a, b = int(n * train_ratio), int(n * (train_ratio + val_ratio))
+        if split == "train":
+            self.data = df[:a].reset_index(drop=True)
+        elif split == "val":
+            self.data = df[a:b].reset_index(drop=True)
+        elif split == "test":
+            self.data = df[b:].reset_index(drop=True)
+        else:
+            raise ValueError(f"Invalid split: {split}")
+
+    @staticmethod
+    def _ids_to_text(ids):
+        out = ""
+        for u in ids:
+            try:
+                if isinstance(u, str) and u.startswith("U+"):
+                    out += chr(int(u[2:], 16))
+            except (ValueError, OverflowError):
+                continue
+        return out
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        import torch
+        from PIL import Image
+        row = self.data.iloc[idx]
+        rel = row["column_image"]
+        path = rel if rel.startswith(self.image_root) else os.path.join(self.image_root, os.path.basename(rel))
+        try:
+            px = image_to_tensor(resize_with_padding(Image.open(path).convert("RGB"), self.image_size))
+        except Exception:
+            px = torch.zeros(3, self.image_size[0], self.image_size[1])
+        enc = self.tokenizer(row["text"], max_length=self.max_length, padding="max_length", truncation=True,
+                             return_tensors="pt")
+        return {"pixel_values": px, "labels": enc["input_ids"].squeeze(0), "text": row["text"], "image_path": path}
+
+
+def collate(items):
+    import torch
+    return {"pixel_values": torch.stack([i["pixel_values"] for i in items]),
+            "labels": torch.stack([i["labels"] for i in items]),
+            "text": [i["text"] for i in items], "image_path": [i["image_path"] for i in items]}
+
+
+def make_loader(dataset, batch_size, shuffle, seed=42, rank=0, world=1, drop_last=False):
+    """DataLoader with a DistributedSampler-style shard (every rank sees len/world samples of the same permutation)."""
+    import torch
+    from torch.utils.data import DataLoader, Subset
+    idx = list(range(len(dataset)))
+    if shuffle:
+        g = torch.Generator().manual_seed(seed)
+        idx = torch.randperm(len(dataset), generator=g).tolist()
+    if world > 1:
+        per = (len(idx) + world - 1) // world
+        idx = (idx + idx[: per * world - len(idx)])[rank::world]
+    return DataLoader(Subset(dataset, idx), batch_size=batch_size, shuffle=False, collate_fn=collate, drop_last=drop_last)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""CLI entrypoint of the MI355X engine: the flag surface of scripts/train_trocr.py:23-71 (TrOCR) plus the
+ocr_lightning/train.py:161-189 spellings, wired to kzv.TrOCRModel + kzv.trainer.fit.
+
+  python -m kzv.train --synthetic 64 --batch_size 32 --encoder_hidden_size 384 --encoder_num_layers 6 \
+         --encoder_num_heads 6 --image_size 64 640 --max_epochs 1            # BASELINE.json configs[0] plumbing
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m kzv.train --gpus 8 ...
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import tempfile
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Train TrOCR model (MI355X engine)")
+    # data (scripts/train_trocr.py:27-36)
+    p.add_argument("--csv_path", type=str, default="data/processed_v2/column_info.csv")
+    p.add_argument("--image_root", type=str, default="data/processed_v2/column_images")
+    p.add_argument("--decoder_path", type=str,
+                   default="experiments/pretrain_language_model/roberta-small-japanese-aozora-char/20250530_034458/checkpoint-200000")
+    p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic line crops (no CSV / checkpoint needed)")
+    p.add_argument("--train_data_dir", type=str, default=None, help="ocr_lightning/train.py spelling (unused by TrOCR)")
+    p.add_argument("--val_data_dir", type=str, default=None, help="ocr_lightning/train.py spelling (unused by TrOCR)")
+    # model (:39-44)
+    p.add_argument("--image_size", type=int, nargs=2, default=[1024, 64])
+    p.add_argument("--patch_size", type=int, nargs=2, default=[16, 16])
+    p.add_argument("--encoder_hidden_size", type=int, default=768)
+    p.add_argument("--encoder_num_layers", type=int, default=12)
+    p.add_argument("--encoder_num_heads", type=int, default=8)
+    p.add_argument("--max_length", type=int, default=128)
+    # training (:47-54)
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--learning_rate", type=float, default=1e-4)
+    p.add_argument("--weight_decay", type=float, default=0)
+    p.add_argument("--beta1", type=float, default=0.9)
+    p.add_argument("--beta2", type=float, default=0.999)
+    p.add_argument("--epsilon", type=float, default=1e-8)
+    p.add_argument("--max_epochs", type=int, default=50)
+    p.add_argument("--max_steps", type=int, default=-1)
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--train_ratio", type=float, default=0.8)
+    p.add_argument("--val_ratio", type=float, default=0.1)
+    p.add_argument("--test_ratio", type=float, default=0.1)
+    # output (:62-63)
+    p.add_argument("--output_dir", type=str, default="experiments/trocr")
+    p.add_argument("--experiment_name", type=str, default="trocr_vit_roberta")
+    # hardware (:66-69 and ocr_lightning/train.py:182-186)
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--devices", type=str, default=None, help="ocr_lightning spelling of --gpus")
+    p.add_argument("--accelerator", type=str, default="gpu")
+    p.add_argument("--precision", type=str, default="bf16-mixed", choices=["16-mixed", "32", "bf16-mixed"])
+    p.add_argument("--seed", type=int, default=42)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    import torch
+    from .config import ModelConfig
+    from .data import LineCsvDataset, SyntheticLineDataset, build_decoder_dir, make_loader
+    from .model import TrOCRModel
+    from .trainer import fit, init_distributed
+
+    if args.devices is not None:
+        args.gpus = int(args.devices) if str(args.devices).isdigit() else len(str(args.devices).split(","))
+    if args.accelerator != "gpu" or args.gpus < 1:
+        raise SystemExit("this engine runs on MI355X GPUs only (the reference CPU Trainer branch is not provided)")
+    if args.precision != "bf16-mixed":
+        raise SystemExit("the engine implements bf16-mixed (scripts/train_trocr.py:68 default) only")
+    if args.encoder_hidden_size != 64 * args.encoder_num_heads:
+        raise SystemExit("head_dim must be 64: --encoder_hidden_size must equal 64 * --encoder_num_heads")
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU with torch.distributed.run")
+    torch.manual_seed(args.seed)
+    out_dir = os.path.join(args.output_dir, args.experiment_name)
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        print(f"Output directory: {out_dir}\nDecoder path: {args.decoder_path}")
+    tmp = None
+    decoder_path = args.decoder_path
+    if args.synthetic and not os.path.exists(decoder_path):
+        tmp = tempfile.TemporaryDirectory()
+        decoder_path = build_decoder_dir(os.path.join(tmp.name, "decoder"), ModelConfig(max_pos=max(128, args.max_length)))
+    if not os.path.exists(decoder_path):
+        raise FileNotFoundError(f"Decoder path not found: {decoder_path}")      # scripts/train_trocr.py:88-89
+    encoder_config = {"image_size": tuple(args.image_size), "patch_size": tuple(args.patch_size), "num_channels": 3,
+                      "hidden_size": args.encoder_hidden_size, "num_hidden_layers": args.encoder_num_layers,
+                      "num_attention_heads": args.encoder_num_heads, "intermediate_size": args.encoder_hidden_size * 4,
+                      "hidden_dropout_prob": 0.1, "attention_probs_dropout_prob": 0.1}   # :111-121
+    model = TrOCRModel(encoder_config, decoder_path, learning_rate=args.learning_rate, beta1=args.beta1, beta2=args.beta2,
+                       epsilon=args.epsilon, weight_decay=args.weight_decay, device=f"cuda:{local}", init_seed=args.seed)
+    model._step_seed = 1_000_003 * rank
+    if args.synthetic:
+        n_val = max(args.batch_size, args.synthetic // 10)
+        train_ds = SyntheticLineDataset(model.cfg, args.synthetic, args.max_length, seed=args.seed)
+        val_ds = SyntheticLineDataset(model.cfg, n_val, args.max_length, seed=args.seed + 1)
+    else:
+        kw = dict(csv_path=args.csv_path, image_root=args.image_root, tokenizer=model.tokenizer, image_size=tuple(args.image_size),
+                  max_length=args.max_length, train_ratio=args.train_ratio, val_ratio=args.val_ratio, test_ratio=args.test_ratio)
+        train_ds, val_ds = LineCsvDataset(split="train", **kw), LineCsvDataset(split="val", **kw)
+    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, drop_last=True)
+    val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world)
+    if rank == 0:
+        print(f"Train samples: {len(train_ds)}\nVal samples: {len(val_ds)}\nParameters: {model.num_parameters():,}")
+    hist = fit(model, train_loader, val_loader, max_epochs=args.max_epochs, max_steps=args.max_steps, log_every=50,
+               val_check_interval=0.5, ckpt_dir=os.path.join(out_dir, "checkpoints"), world=world, rank=rank)
+    if rank == 0:
+        print(f"Training completed! Checkpoints saved to: {os.path.join(out_dir, 'checkpoints')}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    if tmp is not None:
+        tmp.cleanup()
+    return hist
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() is not None else 1)
