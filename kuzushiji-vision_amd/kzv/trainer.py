@@ -27,6 +27,10 @@ def init_distributed(backend: str | None = None):
     import torch
     import torch.distributed as dist
     rank, world, local = dist_env()
+    # rehearsal knobs (1-GPU dev boxes): several ranks on one device over gloo
+    if os.environ.get("KZV_FORCE_DEVICE") is not None:
+        local = int(os.environ["KZV_FORCE_DEVICE"])
+    backend = backend or os.environ.get("KZV_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
