@@ -161,26 +161,50 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 }
 
 // =============================================================================================== backward
+// LDS budget <= 80 KiB so TWO workgroups share a CU (one stages / waits at a barrier while the other computes):
+// K and V images stay resident; Q and dO come in 32-query slabs through a 2-deep ring (the slab of block qb+1
+// is in flight during block qb); dS for the current slab only.
 constexpr int DS_STRIDE = SP * 2 + 16;          // bytes per dS row (pad keeps 16-B reads conflict-light)
 constexpr int DS_BYTES = 32 * DS_STRIDE;
-constexpr int BWD_LDS = 4 * IMG + 2 * DS_BYTES + 3 * SP * 4;
+constexpr int SLAB = 32 * 128;                  // 32 rows x 64 bf16
+constexpr int BWD_LDS = 2 * IMG + 4 * SLAB + DS_BYTES + 3 * SP * 4;
+static_assert(BWD_LDS <= 80 * 1024, "attention backward must fit two workgroups per CU");
+
+// stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces, wave w issues piece w of each
+__device__ __forceinline__ void stage_slabs(char* qs, char* os, const bf16_t* Qb, const bf16_t* dOb, int64_t ldq, int64_t ldo,
+                                            int row0, int nvalid, const void* zero16, int w, int lane) {
+    const int row = w * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const bool ok = row0 + row < nvalid;
+    glds16_asm(ok ? (const void*)(Qb + (int64_t)(row0 + row) * ldq + chunk * 8) : zero16, qs + w * 1024);
+    glds16_asm(ok ? (const void*)(dOb + (int64_t)(row0 + row) * ldo + chunk * 8) : zero16, os + w * 1024);
+}
+__device__ __forceinline__ void stage_image_asm(char* img, const bf16_t* src, int64_t ld, int nvalid, const void* zero16,
+                                                int w, int lane) {
+    const int r8 = lane >> 3;
+    for (int pc = w; pc < SP / 8; pc += 4) {
+        const int row = pc * 8 + r8;
+        const int chunk = (lane & 7) ^ (row & 7);
+        glds16_asm(row < nvalid ? (const void*)(src + (int64_t)row * ld + chunk * 8) : zero16, img + pc * 1024);
+    }
+}
 
 template <int MODE>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qs = smem; char* Os = smem + IMG; char* Ks = smem + 2 * IMG; char* Vs = smem + 3 * IMG;
-    char* dSb = smem + 4 * IMG;
-    float* lse = (float*)(dSb + 2 * DS_BYTES);
+    char* Ks = smem; char* Vs = smem + IMG;
+    char* Qring = smem + 2 * IMG; char* Oring = Qring + 2 * SLAB;
+    char* dS = Oring + 2 * SLAB;
+    float* lse = (float*)(dS + DS_BYTES);
     float* dlt = lse + SP;
     int* kvalid = (int*)(dlt + SP);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
     const bf16_t* Qb = p.Q + (int64_t)b * p.Sq * p.ldq + h * 64;
     const bf16_t* dOb = p.dO + (int64_t)b * p.Sq * p.ldo + h * 64;
-    stage_image(Qs, Qb, p.ldq, p.Sq, p.zero16, w, lane);
-    stage_image(Os, dOb, p.ldo, p.Sq, p.zero16, w, lane);
-    stage_image(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
-    stage_image(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    stage_image_asm(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image_asm(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    stage_slabs(Qring, Oring, Qb, dOb, p.ldq, p.ldo, 0, p.Sq, p.zero16, w, lane);
     if (tid < SP) {
         kvalid[tid] = tid < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + tid] != p.pad_id);
         float l = INFINITY, d = 0.f;
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
         }
         lse[tid] = l * LOG2E; dlt[tid] = d;
     }
-    for (int i = tid; i < 2 * DS_BYTES / 16; i += 256) ((uint4*)dSb)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
+    for (int i = tid; i < DS_BYTES / 16; i += 256) ((uint4*)dS)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -210,14 +234,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
         for (int d = 0; d < 4; ++d) { dk[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     for (int qb = 0; qb < nqb; ++qb) {
-        char* dS = dSb + (qb & 1) * DS_BYTES;
+        const char* Qs = Qring + (qb & 1) * SLAB;
+        const char* Os = Oring + (qb & 1) * SLAB;
+        if (qb + 1 < nqb)      // next slab flies during this block's two phases
+            stage_slabs(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, p.ldq, p.ldo, (qb + 1) * 32, p.Sq, p.zero16, w, lane);
         // ---------------- phase A: per owned key tile, S / dP / P / dS for 32 queries; dV^T, dK^T ----------
-        // A operands shared by all key tiles of this wave: dO^T and Q^T fragments over the 32 queries
-        bf16x8 dOt[4], Qt[4];
+        bf16x8 dOt[4], Qt[4];     // A operands shared by all key tiles of this wave: dO^T and Q^T over the slab
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            dOt[dt] = cat8(frag_tr(Os, qb * 32 + 4 * g, dt * 2, l15), frag_tr(Os, qb * 32 + 16 + 4 * g, dt * 2, l15));
-            Qt[dt] = cat8(frag_tr(Qs, qb * 32 + 4 * g, dt * 2, l15), frag_tr(Qs, qb * 32 + 16 + 4 * g, dt * 2, l15));
+            dOt[dt] = cat8(frag_tr(Os, 4 * g, dt * 2, l15), frag_tr(Os, 16 + 4 * g, dt * 2, l15));
+            Qt[dt] = cat8(frag_tr(Qs, 4 * g, dt * 2, l15), frag_tr(Qs, 16 + 4 * g, dt * 2, l15));
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
             float pd[8], ds[8];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                const int qrow = qb * 32 + t2 * 16 + l15;
+                const int qrow = t2 * 16 + l15;
                 f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
                 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, g), k0, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, 4 + g), k1, S, 0, 0, 0);
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
                 for (int r = 0; r < 4; ++r) {
                     const int q = qb * 32 + t2 * 16 + 4 * g + r;
                     const bool ok = kok && (MODE == 0 || key <= q);
-                    float pr = ok ? exp2f(S[r] * sc - lse[q]) : 0.f;      // lse = +inf for q >= Sq / dead rows
+                    float pr = ok ? __builtin_amdgcn_exp2f(S[r] * sc - lse[q]) : 0.f;      // lse = +inf for q >= Sq / dead rows
                     float kp = 1.f;
                     if (p.thr16) kp = keep_of(p, (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)p.Sk + key);
                     pd[t2 * 4 + r] = pr * kp;
@@ -288,8 +314,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnP p) {
                 }
             }
         }
-        // no barrier here: the next slab writes the OTHER dS buffer; the barrier after its phase A orders
-        // this slab's phase-B reads before the slab after next overwrites this buffer.
+        // the next slab (this wave's pieces) has landed; the barrier publishes everyone's pieces and frees dS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int MAXC = 8;  // float4 chunks per lane -> H <= 2048
+constexpr int MAXC = 8;  // float4 chunks per lane -> H <= 2048 (kernels are instantiated per chunk count: registers = occupancy)
 
 struct LnFwd {
     const float* x; const float* gamma; const float* beta; bf16_t* y16; float* y32; float* stats;
@@ -24,23 +24,24 @@ struct LnFwd {
     unsigned thr16; float inv_keep; unsigned key;
 };
 
+template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const int nc = p.H >> 2;
     const float4* xr = (const float4*)(p.x + (int64_t)row * p.H);
-    float4 v[MAXC];
+    float4 v[NC];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int i = lane + c * 64;
         if (i < nc) { v[c] = xr[i]; s += v[c].x + v[c].y + v[c].z + v[c].w; }
     }
     const float mean = wave_sum(s) / (float)p.H;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int i = lane + c * 64;
         if (i < nc) {
             const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
         orow = row - row / p.seq - 1;
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int i = lane + c * 64;
         if (i < nc) {
             const float4 gm = ((const float4*)p.gamma)[i], bt = ((const float4*)p.beta)[i];
@@ -82,13 +83,14 @@ struct LnBwd {
 
 constexpr int BWD_ROWS = 32;  // rows per workgroup (4 waves x 8)
 
+template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nc = p.H >> 2;
-    float4 dg[MAXC], db[MAXC];
+    float4 dg[NC], db[NC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) { dg[c] = make_float4(0, 0, 0, 0); db[c] = make_float4(0, 0, 0, 0); }
+    for (int c = 0; c < NC; ++c) { dg[c] = make_float4(0, 0, 0, 0); db[c] = make_float4(0, 0, 0, 0); }
     const float invH = 1.f / (float)p.H;
     for (int rr = 0; rr < BWD_ROWS / 4; ++rr) {
         const int row = blockIdx.x * BWD_ROWS + rr * 4 + w;
@@ -101,10 +103,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
         }
         const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
         const float4* xr = (const float4*)(p.x + (int64_t)row * p.H);
-        float4 xh[MAXC], gy[MAXC];
+        float4 xh[NC], gy[NC], prev[NC];
         float s1 = 0.f, s2 = 0.f;
+        float4* dxr = (float4*)(p.dx + (int64_t)row * p.H);
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {          // issue the accumulate-into loads with the others (latency overlap)
+            const int i = lane + c * 64;
+            prev[c] = (p.accumulate && i < nc) ? dxr[i] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
             const int i = lane + c * 64;
             if (i < nc) {
                 const float4 xv = xr[i];
@@ -132,14 +140,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
             }
         }
         const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
-        float4* dxr = (float4*)(p.dx + (int64_t)row * p.H);
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int i = lane + c * 64;
             if (i < nc) {
                 float4 o = make_float4(rstd * (gy[c].x - m1 - xh[c].x * m2), rstd * (gy[c].y - m1 - xh[c].y * m2),
                                        rstd * (gy[c].z - m1 - xh[c].z * m2), rstd * (gy[c].w - m1 - xh[c].w * m2));
-                if (p.accumulate) { const float4 a = dxr[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                o.x += prev[c].x; o.y += prev[c].y; o.z += prev[c].z; o.w += prev[c].w;
                 dxr[i] = o;
             }
         }
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
     float4* sg = (float4*)smem + (w * 2) * nc;
     float4* sb = sg + nc;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int i = lane + c * 64;
         if (i < nc) { sg[i] = dg[c]; sb[i] = db[c]; }
     }
@@ -171,7 +178,13 @@ int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y
     if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
     LnFwd p{x, gamma, beta, (bf16_t*)y16, y32, stats, rows, H, seq > 0 ? seq : 1, drop_first, eps, 0, 1.f, drop_key};
     kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+    const int ncl = (H / 4 + 63) / 64;
+    const dim3 grid((rows + 3) / 4);
+    if (ncl <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, p);
+    else if (ncl == 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, p);
+    else if (ncl == 3) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, s, p);
+    else if (ncl == 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, s, p);
     return kzv_check_launch("layernorm_fwd");
 }
 
@@ -182,7 +195,14 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
     LnBwd p{dy, x, stats, gamma, dx, dgamma, dbeta, rows, H, seq > 0 ? seq : 1, drop_first, dy_is_f32, accumulate_dx, 0, 1.f, drop_key};
     kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + BWD_ROWS - 1) / BWD_ROWS), dim3(256), 8 * H * sizeof(float), s, p);
+    const int ncl = (H / 4 + 63) / 64;
+    const dim3 grid((rows + BWD_ROWS - 1) / BWD_ROWS);
+    const size_t lds = 8 * H * sizeof(float);
+    if (ncl <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), lds, s, p);
+    else if (ncl == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), lds, s, p);
+    else if (ncl == 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, dim3(256), lds, s, p);
+    else if (ncl == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), lds, s, p);
     return kzv_check_launch("layernorm_bwd");
 }
 
