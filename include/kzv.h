@@ -125,6 +125,7 @@ typedef struct kzv_gemm_tn_args {
     const void* Q; int64_t ldq;       /* bf16 [Mtok, K] */
     float* OUT; int64_t ldo;          /* fp32 [n_store, K] accumulated into */
     int32_t Mtok, N, K, n_store;
+    float* dbias;                     /* optional fp32 [n_store]: += column sums of P (bias gradient) */
 } kzv_gemm_tn_args;
 int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream);
 

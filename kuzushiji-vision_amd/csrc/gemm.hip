@@ -46,12 +46,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Workgroup = WM x WN waves, each wave a 64x64 output tile (4x4 MFMA 16x16x32 tiles); block tile
 // BM = 64*WM rows by BN = 64*WN columns; NSTAGE-deep LDS ring of [BM + BN][64] bf16 stages filled by
 // LDS-DMA.  NSTAGE-2 stages stay in flight ACROSS the per-step barrier (counted vmcnt + raw s_barrier).
-template <int EPI, int WM, int WN, int NSTAGE>
+// KB = reduction depth of one stage (64 or 32).  KB = 32 halves the ring (more workgroups per CU); its 64-byte
+// rows use the swizzle chunk ^ perm[(row >> 2) & 3], perm = {0,2,3,1} (conflict-free for the ds_read_b128 lane
+// groups, derived like the 128-byte-row case).  ASM_DMA issues the LDS-DMA from inline asm (needed for rings
+// deeper than 2: hipcc must not see the in-flight DMA or it drains it before every LDS read).
+template <int EPI, int WM, int WN, int NSTAGE, int KB, bool ASM_DMA>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p) {
     constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
-    constexpr int STAGE = (BM + BN) * BK * 2;
-    constexpr int PPW = (BM + BN) / 8 / NW;          // 1-KiB LDS-DMA pieces per wave per stage
-    static_assert((BM + BN) / 8 % NW == 0, "pieces must divide over the waves");
+    constexpr int ROWB = KB * 2, SPR = ROWB / 16, RPP = 1024 / ROWB;   // row bytes, 16-B slots per row, rows per piece
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int PPW = (BM + BN) / RPP / NW;        // 1-KiB LDS-DMA pieces per wave per stage
+    static_assert((BM + BN) / RPP % NW == 0, "pieces must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
@@ -66,27 +71,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
     // (involution; the fragment read applies the same XOR).
     const char* src[PPW]; int inc[PPW];
     {
-        const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+        const int rl = lane / SPR;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int row = (w + j * NW) * 8 + r8;
+            const int row = (w + j * NW) * RPP + rl;
+            const int chunk = (lane % SPR) ^ (KB == 64 ? (row & 7) : ((0x1320 >> (((row >> 2) & 3) * 4)) & 3));
             if (row < BM) {
                 const int am = tm * BM + row;
                 const bool v = am < p.M;
                 src[j] = v ? (const char*)(p.A + (int64_t)am * p.lda + chunk * 8) : (const char*)p.zero16;
-                inc[j] = v ? BK * 2 : 0;
+                inc[j] = v ? ROWB : 0;
             } else {
                 const int bn = tn * BN + row - BM;
                 const bool v = bn < p.n_valid;
                 src[j] = v ? (const char*)(p.B + (int64_t)bn * p.ldb + chunk * 8) : (const char*)p.zero16;
-                inc[j] = v ? BK * 2 : 0;
+                inc[j] = v ? ROWB : 0;
             }
         }
     }
     auto stage = [&](int s) {
         char* d = smem + s * STAGE + w * 1024;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) { glds16(src[j], d + j * NW * 1024); src[j] += inc[j]; }
+        for (int j = 0; j < PPW; ++j) {
+            if constexpr (ASM_DMA) glds16_asm(src[j], d + j * NW * 1024); else glds16(src[j], d + j * NW * 1024);
+            src[j] += inc[j];
+        }
     };
 
     f32x4 acc[4][4];
@@ -96,20 +105,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets inside a stage (row-major 128-B rows, XOR-swizzled 16-B slots)
-    const int a_row_off = (wm * 64 + l15) * 128;
-    const int b_row_off = BM * BK * 2 + (wn * 64 + l15) * 128;
-    const int sw = lane & 7;
+    const int a_row_off = (wm * 64 + l15) * ROWB;
+    const int b_row_off = BM * ROWB + (wn * 64 + l15) * ROWB;
+    const int sw = KB == 64 ? (lane & 7) : ((0x1320 >> (((lane >> 2) & 3) * 4)) & 3);   // rows i*16 + l15: (row>>2)&3 == (l15>>2)
 
     auto compute = [&](int s) {
         const char* base = smem + s * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KB / 32; ++ks) {
             const int slot = ((ks * 4 + g) ^ sw) << 4;
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(base + a_row_off + i * 16 * 128 + slot);
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(base + a_row_off + i * 16 * ROWB + slot);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(base + b_row_off + j * 16 * 128 + slot);
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(base + b_row_off + j * 16 * ROWB + slot);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
     // ring schedule: stages t+1 .. t+NSTAGE-2 are in flight while stage t is consumed.  The barrier at the
     // top of step t (a) publishes every wave's stage-t pieces (each wave waited for its own) and (b) proves
     // every wave finished reading buffer (t-1)%NSTAGE, which stage t+NSTAGE-1 then overwrites.
-    const int nk = p.K / BK;
+    const int nk = p.K / KB;
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nk) stage(s);
@@ -140,43 +149,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
     // Accumulators (lane: C[m = i*16 + l15][n0 = j*16 + 4g .. +3]) go through LDS (the ring is free now) so
     // that global traffic is row-contiguous: one thread = 4 consecutive columns, 32 threads = one 128-column
     // row (256 B of bf16 / 512 B of fp32 per row per instruction, residual/aux loads included).
-    static_assert(NSTAGE * STAGE >= BM * BN * 4, "LDS ring too small to stage the fp32 tile");
-    __syncthreads();
-    float* tile = (float*)smem;                       // [BM][BN] fp32, 16-B chunks XOR-swizzled by (row & 31)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ml = wm * 64 + i * 16 + l15, c = wn * 16 + j * 4 + g;
-            *(f32x4*)(tile + ml * BN + ((c ^ (ml & 31)) << 2)) = acc[i][j];
-        }
-    __syncthreads();
+    // The tile is staged RC rows at a time (RC = all BM rows when the ring is large enough, else 64).
+    constexpr int RC = NSTAGE * STAGE >= BM * BN * 4 ? BM : 64;
+    static_assert(NSTAGE * STAGE >= RC * BN * 4, "LDS ring too small to stage 64 rows of the fp32 tile");
+    float* tile = (float*)smem;                       // [RC][BN] fp32, 16-B chunks XOR-swizzled by (row & 31)
     constexpr int CPR = BN / 4, RSTEP = NW * 64 / CPR;
     const int c = tid % CPR;
     const int n0 = tn * BN + c * 4;
-    if (n0 >= p.N) return;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI != KZV_EPI_DGELU && p.bias) {
+    if (EPI != KZV_EPI_DGELU && p.bias && n0 < p.N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b4[r] = (n0 + r < p.n_valid) ? p.bias[n0 + r] : 0.f;
     }
+#pragma unroll
+  for (int r0 = 0; r0 < BM; r0 += RC) {
+    __syncthreads();                                  // ring (or the previous chunk) is no longer being read
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = wm * 64 + i * 16 + l15 - r0;
+        if (ml >= 0 && ml < RC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = wn * 16 + j * 4 + g;
+                *(f32x4*)(tile + ml * BN + ((cc ^ (ml & 31)) << 2)) = acc[i][j];
+            }
+        }
+    }
+    __syncthreads();
+    if (n0 < p.N) {
     // rows are processed 8 at a time with the residual / aux loads of the batch issued up front, so the
     // per-row global-load latency overlaps instead of serialising 16 dependent round trips per tile
-    constexpr int NP = BM / RSTEP;
+    constexpr int NP = RC / RSTEP;
     static_assert(NP % 8 == 0, "row passes come in batches of 8");
 #pragma unroll
     for (int pb = 0; pb < NP; pb += 8) {
         float4 r4[8]; uint2 u2[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int m = tm * BM + tid / CPR + (pb + q) * RSTEP;
+            const int m = tm * BM + r0 + tid / CPR + (pb + q) * RSTEP;
             if (EPI == KZV_EPI_RESID) r4[q] = m < p.M ? *(const float4*)(p.resid + (int64_t)m * p.ldr + n0) : make_float4(0, 0, 0, 0);
             if (EPI == KZV_EPI_DGELU) u2[q] = m < p.M ? *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0) : make_uint2(0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int rr = tid / CPR + (pb + q) * RSTEP;
-            const int m = tm * BM + rr;
+            const int m = tm * BM + r0 + rr;
             if (m >= p.M) continue;
             const f32x4 a4 = *(const f32x4*)(tile + rr * BN + ((c ^ (rr & 31)) << 2));
             float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
@@ -211,6 +228,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
             }
         }
     }
+    }   // n0 < N
+  }     // row chunks
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,6 +241,7 @@ struct TnParams {
     const bf16_t* P; const bf16_t* Q; float* OUT; const void* zero16;
     int64_t ldp, ldq, ldo;
     int Mtok, N, K, n_store, splits, chunk;   // chunk = tokens per split (multiple of 64)
+    float* dbias;                              // optional: dbias[n] += sum_t P[t][n]  (the nn.Linear bias gradient)
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
@@ -285,7 +305,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int sub8 = (l15 & 1) * 8;                // which 8-byte half of the 16-B chunk
     const int cq = l15 >> 1 & 1;                   // chunk within the 16-col block (2 chunks of 8 cols)
 
-    auto compute = [&](int s) {
+    // Bias gradient for free: column sums of P are one more MFMA against a vector of ones.  Every (n-tile, split)
+    // is visited by tilesK workgroups (one per k-tile) that stream the same P panel, so workgroup tkb takes the
+    // reduction steps t with t % tilesK == tkb: each token is summed exactly once and the extra MFMAs (4 per 32
+    // tokens, waves with wk == 0 only) spread evenly over the grid.
+    f32x4 bacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = (bf16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bool bias_wave = p.dbias != nullptr && wk == 0;
+
+    auto compute = [&](int s, bool with_bias) {
         const char* bP = smem + s * STAGE_BYTES;
         const char* bQ = bP + 64 * 256;
 #pragma unroll
@@ -311,6 +341,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[j], fq[i], acc[i][j], 0, 0, 0);
+            if (with_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[j], ones, bacc[j], 0, 0, 0);
+            }
         }
     };
 
@@ -322,8 +356,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         __builtin_amdgcn_s_barrier();                        // ... and everybody's; buffer cur^1 is free again
         asm volatile("" ::: "memory");
         if (t + 1 < nt) stage(cur ^ 1, t_begin + (t + 1) * 64);
-        compute(cur);
+        compute(cur, bias_wave && (t % tilesK) == tkb);
         cur ^= 1;
+    }
+    if (bias_wave && l15 == 0) {     // every column of bacc holds the same sums; column 0 publishes them
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tnb * 128 + wn * 64 + j * 16 + 4 * g + r;
+                if (n < p.n_store) atomicAdd(p.dbias + n, bacc[j][r]);
+            }
     }
 
     // ---- epilogue: accumulators -> LDS (fp32 [128 n][128 k], 16-B chunks XOR-swizzled by row) -> each
@@ -363,7 +406,7 @@ static int kzv_nt_variant() {
 extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return kzv_fail(KZV_E_ARG, "gemm_nt: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return kzv_fail(KZV_E_ARG, "gemm_nt: empty shape");
-    if (a->K % BK) return kzv_fail(KZV_E_ARG, "gemm_nt: K must be a multiple of 64");
+    if (a->K % 64) return kzv_fail(KZV_E_ARG, "gemm_nt: K must be a multiple of 64");
     if (a->N % 4 || a->ldc % 4) return kzv_fail(KZV_E_ARG, "gemm_nt: N and ldc must be multiples of 4");
     if (a->lda % 8 || a->ldb % 8) return kzv_fail(KZV_E_ARG, "gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
     if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return kzv_fail(KZV_E_ARG, "gemm_nt: operands must be 16-byte aligned");
@@ -379,22 +422,28 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.drop_key = a->drop_key;
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
-#define KZV_NT_CASE(E, WM, WN, NS)                                                                        \
+#define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \
     case E: {                                                                                             \
-        constexpr int lds = NS * (WM + WN) * 64 * BK * 2;                                                 \
+        constexpr int lds = NS * (WM + WN) * 64 * KB * 2;                                                 \
         static bool attr_done = false;                                                                    \
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<E, WM, WN, NS, KB, AD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
         const int grid = ((a->M + WM * 64 - 1) / (WM * 64)) * ((a->N + WN * 64 - 1) / (WN * 64));         \
-        hipLaunchKernelGGL((gemm_nt_kernel<E, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);   \
+        hipLaunchKernelGGL((gemm_nt_kernel<E, WM, WN, NS, KB, AD>), dim3(grid), dim3(WM * WN * 64), lds, s, p); \
     } break;
-#define KZV_NT_VARIANT(WM, WN, NS)                                                                        \
+#define KZV_NT_VARIANT(WM, WN, NS, KB, AD)                                                                \
     switch (epilogue) {                                                                                   \
-        KZV_NT_CASE(KZV_EPI_BF16, WM, WN, NS) KZV_NT_CASE(KZV_EPI_F32, WM, WN, NS)                        \
-        KZV_NT_CASE(KZV_EPI_GELU, WM, WN, NS) KZV_NT_CASE(KZV_EPI_RESID, WM, WN, NS)                      \
-        KZV_NT_CASE(KZV_EPI_DGELU, WM, WN, NS) KZV_NT_CASE(KZV_EPI_GELU_F32, WM, WN, NS)                  \
+        KZV_NT_CASE(KZV_EPI_BF16, WM, WN, NS, KB, AD) KZV_NT_CASE(KZV_EPI_F32, WM, WN, NS, KB, AD)        \
+        KZV_NT_CASE(KZV_EPI_GELU, WM, WN, NS, KB, AD) KZV_NT_CASE(KZV_EPI_RESID, WM, WN, NS, KB, AD)      \
+        KZV_NT_CASE(KZV_EPI_DGELU, WM, WN, NS, KB, AD) KZV_NT_CASE(KZV_EPI_GELU_F32, WM, WN, NS, KB, AD)  \
         default: return kzv_fail(KZV_E_ARG, "gemm_nt: unknown epilogue");                                 \
     }
-    KZV_NT_VARIANT(2, 2, 2)
+    switch (kzv_nt_variant()) {
+        case 1: KZV_NT_VARIANT(2, 2, 2, 32, false) break;
+        case 2: KZV_NT_VARIANT(2, 2, 3, 32, true) break;
+        case 3: KZV_NT_VARIANT(2, 2, 4, 32, true) break;
+        case 4: KZV_NT_VARIANT(2, 2, 2, 64, true) break;
+        default: KZV_NT_VARIANT(2, 2, 2, 64, false) break;
+    }
 #undef KZV_NT_VARIANT
 #undef KZV_NT_CASE
     return kzv_check_launch("gemm_nt");
@@ -410,6 +459,7 @@ extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
     if (!p.zero16) return kzv_fail(KZV_E_HIP, "gemm_tn: zero page unavailable");
     p.ldp = a->ldp; p.ldq = a->ldq; p.ldo = a->ldo;
     p.Mtok = a->Mtok; p.N = a->N; p.K = a->K; p.n_store = a->n_store > 0 ? a->n_store : a->N;
+    p.dbias = a->dbias;
     const int tiles = ((a->N + 127) / 128) * ((a->K + 127) / 128);
     const int tok_tiles = (a->Mtok + 63) / 64;
     // Token splits: fill the 512 resident slots (256 CUs x 2 workgroups) in ONE round without overshooting

@@ -9,7 +9,8 @@ int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y
                   int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s);
 int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
                   int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
-                  float drop_p, uint32_t drop_key, hipStream_t s);
+                  float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16 = nullptr, float out_drop_p = 0.f,
+                  uint32_t out_drop_key = 0);
 
 // elementwise.hip
 int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s);

@@ -79,6 +79,7 @@ struct LnBwd {
     float* dx; float* dgamma; float* dbeta;
     int rows, H, seq, drop_first, dy_f32, accumulate;
     unsigned thr16; float inv_keep; unsigned key;
+    bf16_t* out16; unsigned o_thr16; float o_inv_keep; unsigned o_key;   // optional: bf16 copy of the TOTAL dx, dropout-masked
 };
 
 constexpr int BWD_ROWS = 32;  // rows per workgroup (4 waves x 8)
@@ -148,6 +149,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
                                        rstd * (gy[c].z - m1 - xh[c].z * m2), rstd * (gy[c].w - m1 - xh[c].w * m2));
                 o.x += prev[c].x; o.y += prev[c].y; o.z += prev[c].z; o.w += prev[c].w;
                 dxr[i] = o;
+                if (p.out16) {   // input of the next "dropout(linear)" backward: mask(dx) in bf16 (same indexing as colsum_kernel)
+                    if (p.o_thr16) {
+                        const unsigned e = (unsigned)row * (unsigned)p.H + 4u * i;
+                        const unsigned b0 = drop_bits(p.o_key, e >> 1), b1 = drop_bits(p.o_key, (e >> 1) + 1);
+                        o.x *= drop_keep(b0, 0, p.o_thr16, p.o_inv_keep); o.y *= drop_keep(b0, 1, p.o_thr16, p.o_inv_keep);
+                        o.z *= drop_keep(b1, 0, p.o_thr16, p.o_inv_keep); o.w *= drop_keep(b1, 1, p.o_thr16, p.o_inv_keep);
+                    }
+                    ((uint2*)(p.out16 + (int64_t)row * p.H))[i] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+                }
             }
         }
     }
@@ -190,11 +200,13 @@ int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y
 
 int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
                   int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
-                  float drop_p, uint32_t drop_key, hipStream_t s) {
+                  float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16, float out_drop_p, uint32_t out_drop_key) {
     if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || rows <= 0) return kzv_fail(KZV_E_ARG, "layernorm_bwd: null/empty");
     if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
-    LnBwd p{dy, x, stats, gamma, dx, dgamma, dbeta, rows, H, seq > 0 ? seq : 1, drop_first, dy_is_f32, accumulate_dx, 0, 1.f, drop_key};
+    LnBwd p{dy, x, stats, gamma, dx, dgamma, dbeta, rows, H, seq > 0 ? seq : 1, drop_first, dy_is_f32, accumulate_dx, 0, 1.f, drop_key,
+            out16, 0, 1.f, out_drop_key};
     kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
+    kzv_drop_params(out_drop_p, &p.o_thr16, &p.o_inv_keep);
     const int ncl = (H / 4 + 63) / 64;
     const dim3 grid((rows + BWD_ROWS - 1) / BWD_ROWS);
     const size_t lds = 8 * H * sizeof(float);

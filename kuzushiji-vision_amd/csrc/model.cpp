@@ -250,10 +250,11 @@ int gemm(const bf16_t* A, int64_t lda, const W16& w, bool transposed, int M, int
     return kzv_gemm_nt(&a, epi, s);
 }
 
-int wgrad(const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok, int N, int K, int n_store, hipStream_t s) {
+int wgrad(const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok, int N, int K, int n_store, hipStream_t s,
+          float* dbias = nullptr) {
     kzv_gemm_tn_args a;
     memset(&a, 0, sizeof(a));
-    a.P = dY; a.ldp = ldp; a.Q = X; a.ldq = ldq; a.OUT = dW; a.ldo = K; a.Mtok = Mtok; a.N = N; a.K = K; a.n_store = n_store;
+    a.P = dY; a.ldp = ldp; a.Q = X; a.ldq = ldq; a.OUT = dW; a.ldo = K; a.Mtok = Mtok; a.N = N; a.K = K; a.n_store = n_store; a.dbias = dbias;
     return kzv_gemm_tn(&a, s);
 }
 
@@ -359,8 +360,7 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     float* P = m->P; float* G = m->G;
     const int CK = m->Ld * 2 * Hd;
     // ---- CE -> LM head ------------------------------------------------------------------------------
-    KZV_TRY(kzv_colsum_bf16(m->dlogits, m->Vp, G + m->hbias, Md, m->Vp, s));   // pad columns are 0; head.bias is padded to Vp
-    KZV_TRY(wgrad(m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, s));
+    KZV_TRY(wgrad(m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, s, G + m->hbias));
     KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
     KZV_TRY(kzv_ln_bwd_ex(m->dhln, 0, m->hd_gelu, m->hd_st, P + m->hln_w, m->dsum_d, 0, G + m->hln_w, G + m->hln_b, Md, Hd, 1, 0, 0.f, 0, s));
     KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
@@ -374,33 +374,30 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
         const uint32_t site = SITE_DEC_L + 8 * i;
         const bf16_t* xh = i ? m->da[i - 1].x3h : m->xd0h;
         // FFN block: x3 = LN(s3), s3 = x2 + drop(fc2(gelu(fc1(x2))))
-        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s3, a.st3, P + d.ln3w, m->dsum_d, 0, G + d.ln3w, G + d.ln3b, Md, Hd, 1, 0, 0.f, 0, s));
-        KZV_TRY(lin_bwd_drop(m->dsum_d, m->dy_d, G + d.fc2b, Md, Hd, dp(m, c.dec_hidden_dropout), key(m, site + 4), s));
-        KZV_TRY(wgrad(m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, s));
+        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s3, a.st3, P + d.ln3w, m->dsum_d, 0, G + d.ln3w, G + d.ln3b, Md, Hd, 1, 0, 0.f, 0, s,
+                              m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 4)));
+        KZV_TRY(wgrad(m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, s, G + d.fc2b));
         KZV_TRY(gemm(m->dy_d, Hd, m->w_dfc2[i], true, Md, Fd, Hd, Fd, nullptr, m->dbig_d, Fd, KZV_EPI_DGELU, s, nullptr, a.pre, Fd));
-        KZV_TRY(kzv_colsum_bf16(m->dbig_d, Fd, G + d.fc1b, Md, Fd, s));
-        KZV_TRY(wgrad(m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, s));
+        KZV_TRY(wgrad(m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, s, G + d.fc1b));
         KZV_TRY(gemm(m->dbig_d, Fd, m->w_dfc1[i], true, Md, Hd, Fd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // cross-attention block: x2 = LN(s2), s2 = x1 + drop(o(CA(q(x1), kv(enc))))
-        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s2, a.st2, P + d.ln2w, m->dsum_d, 0, G + d.ln2w, G + d.ln2b, Md, Hd, 1, 0, 0.f, 0, s));
-        KZV_TRY(lin_bwd_drop(m->dsum_d, m->dy_d, G + d.cob, Md, Hd, dp(m, c.dec_hidden_dropout), key(m, site + 3), s));
-        KZV_TRY(wgrad(m->dy_d, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, s));
+        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s2, a.st2, P + d.ln2w, m->dsum_d, 0, G + d.ln2w, G + d.ln2b, Md, Hd, 1, 0, 0.f, 0, s,
+                              m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 3)));
+        KZV_TRY(wgrad(m->dy_d, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, s, G + d.cob));
         KZV_TRY(gemm(m->dy_d, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
                      m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->np,
                      dp(m, c.dec_attn_dropout), key(m, site + 2), s));
-        KZV_TRY(kzv_colsum_bf16(m->dq_d, Hd, G + d.cqb, Md, Hd, s));
-        KZV_TRY(wgrad(m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, s));
+        KZV_TRY(wgrad(m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, s, G + d.cqb));
         KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // self-attention block: x1 = LN(s1), s1 = x + drop(o(SA(qkv(x))))
-        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s1, a.st1, P + d.ln1w, m->dsum_d, 0, G + d.ln1w, G + d.ln1b, Md, Hd, 1, 0, 0.f, 0, s));
-        KZV_TRY(lin_bwd_drop(m->dsum_d, m->dy_d, G + d.ob, Md, Hd, dp(m, c.dec_hidden_dropout), key(m, site + 1), s));
-        KZV_TRY(wgrad(m->dy_d, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, s));
+        KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s1, a.st1, P + d.ln1w, m->dsum_d, 0, G + d.ln1w, G + d.ln1b, Md, Hd, 1, 0, 0.f, 0, s,
+                              m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 1)));
+        KZV_TRY(wgrad(m->dy_d, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, s, G + d.ob));
         KZV_TRY(gemm(m->dy_d, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
                      m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
-        KZV_TRY(kzv_colsum_bf16(m->dqkv_d, 3 * Hd, G + d.qkvb, Md, 3 * Hd, s));
-        KZV_TRY(wgrad(m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, s));
+        KZV_TRY(wgrad(m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, s, G + d.qkvb));
         KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
     }
     // ---- decoder embeddings: x0 = drop(LN(word + type + pos)) ---------------------------------------------
@@ -408,15 +405,15 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
                           dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
     KZV_TRY(kzv_embed_scatter_bwd(m->dsum_d, m->labels, m->L, m->posids, G + m->word, G + m->dtype, G + m->dpos, B, T, Hd, c.pad_id, s));
     // ---- cross K/V projection of all layers, encoder_decoder_proj, final encoder LN ---------------------------
-    KZV_TRY(kzv_colsum_bf16(m->dckv, CK, G + m->ckv_b, Mp, CK, s));
-    KZV_TRY(wgrad(m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, s));
+    KZV_TRY(wgrad(m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, s, G + m->ckv_b));
     KZV_TRY(gemm(m->dckv, CK, m->w_ckv, true, Mp, Hd, CK, Hd, nullptr, m->denc, Hd, KZV_EPI_BF16, s));
     if (m->has_proj) {
-        KZV_TRY(kzv_colsum_bf16(m->denc, Hd, G + m->proj_b, Mp, Hd, s));
-        KZV_TRY(wgrad(m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, s));
+        KZV_TRY(wgrad(m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, s, G + m->proj_b));
         KZV_TRY(gemm(m->denc, Hd, m->w_proj, true, Mp, He, Hd, He, nullptr, m->denc_out, He, KZV_EPI_BF16, s));
     }
-    KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Se, 1, 0.f, 0, s));
+    // also emits the masked bf16 copy the top ViT layer's fc2 backward starts from
+    KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Se, 1, 0.f, 0, s,
+                          m->Le ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (m->Le - 1) + 2)));
     return KZV_OK;
 }
 
@@ -427,23 +424,23 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     EncAct& a = m->ea[i];
     const EncLayerP& e = m->ep[i];
     // x_out = x_mid + drop(fc2(gelu(fc1(LN2(x_mid)))))
-    KZV_TRY(lin_bwd_drop(m->dx_e, m->dy_e, G + e.fc2b, Me, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 2), s));
-    KZV_TRY(wgrad(m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, s));
+    // on entry dy_e = dropout-masked bf16 copy of dx_e for this layer's fc2 site (written by the LN backward above it)
+    KZV_TRY(wgrad(m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, s, G + e.fc2b));
     KZV_TRY(gemm(m->dy_e, He, m->w_efc2[i], true, Me, Fe, He, Fe, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe));
-    KZV_TRY(kzv_colsum_bf16(m->dbig_e, Fe, G + e.fc1b, Me, Fe, s));
-    KZV_TRY(wgrad(m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, s));
+    KZV_TRY(wgrad(m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, s, G + e.fc1b));
     KZV_TRY(gemm(m->dbig_e, Fe, m->w_efc1[i], true, Me, He, Fe, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
-    KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s));
+    KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s,
+                          m->dy_e, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
     // x_mid = x_in + drop(o(attn(qkv(LN1(x_in)))))
-    KZV_TRY(lin_bwd_drop(m->dx_e, m->dy_e, G + e.ob, Me, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1), s));
-    KZV_TRY(wgrad(m->dy_e, He, a.ctx, He, G + e.ow, Me, He, He, He, s));
+    KZV_TRY(wgrad(m->dy_e, He, a.ctx, He, G + e.ow, Me, He, He, He, s, G + e.ob));
     KZV_TRY(gemm(m->dy_e, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
     KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
                  m->dqkv_e + 2 * He, c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
-    KZV_TRY(kzv_colsum_bf16(m->dqkv_e, 3 * He, G + e.qkvb, Me, 3 * He, s));
-    KZV_TRY(wgrad(m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, s));
+    KZV_TRY(wgrad(m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, s, G + e.qkvb));
     KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
-    KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_in, a.st1, P + e.ln1w, m->dx_e, 1, G + e.ln1w, G + e.ln1b, Me, He, 1, 0, 0.f, 0, s));
+    // ... and the masked copy for the fc2 site of the layer below (layer 0 hands fp32 dx_e to the embedding backward)
+    KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_in, a.st1, P + e.ln1w, m->dx_e, 1, G + e.ln1w, G + e.ln1b, Me, He, 1, 0, 0.f, 0, s,
+                          i > 0 ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (i - 1) + 2)));
     return KZV_OK;
 }
 

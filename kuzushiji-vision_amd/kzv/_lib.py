@@ -39,7 +39,8 @@ class kzv_gemm_nt_args(C.Structure):
 class kzv_gemm_tn_args(C.Structure):
     _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("Q", C.c_void_p), ("ldq", C.c_int64),
                 ("OUT", C.c_void_p), ("ldo", C.c_int64),
-                ("Mtok", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("n_store", C.c_int32)]
+                ("Mtok", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("n_store", C.c_int32),
+                ("dbias", C.c_void_p)]
 
 
 class kzv_attn_args(C.Structure):

@@ -96,10 +96,15 @@ def test_gemm_tn(lib, Mt, N, K):
     Q = torch.randn(Mt, K, device=DEV).bfloat16()
     base = torch.randn(N, K, device=DEV)
     out = base.clone()
-    a = L.kzv_gemm_tn_args(P=Pm.data_ptr(), ldp=N, Q=Q.data_ptr(), ldq=K, OUT=out.data_ptr(), ldo=K, Mtok=Mt, N=N, K=K, n_store=N)
+    db0 = torch.randn(N, device=DEV)
+    db = db0.clone()
+    a = L.kzv_gemm_tn_args(P=Pm.data_ptr(), ldp=N, Q=Q.data_ptr(), ldq=K, OUT=out.data_ptr(), ldo=K, Mtok=Mt, N=N, K=K, n_store=N,
+                           dbias=db.data_ptr())
     L.check(lib.kzv_gemm_tn(C.byref(a), _st()), "gemm_tn")
     ref = Pm.float().t() @ Q.float() + base
     assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item() + 1e-4     # accumulates INTO out
+    # fused bias gradient: dbias += column sums of P (each token counted exactly once across k-tiles and splits)
+    assert (db - db0 - Pm.float().sum(0)).abs().max().item() < 1e-3
 
 
 @pytest.mark.parametrize("rows,H", [(7, 64), (1000, 256), (333, 768), (64, 1024)])
