@@ -11,6 +11,7 @@
 #include "kzv_host.h"
 #include "kzv_kernels.h"
 #include "../../include/kzv.h"
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,10 @@ struct kzv_model {
     // backward scratch
     float *dx_e, *dx_d, *dsum_d;
     bf16_t *dy_e, *dbig_e, *dh_e, *dqkv_e, *dctx_e, *dpatch, *denc_out, *denc, *dckv, *dy_d, *dbig_d, *dqkv_d, *dctx_d, *dq_d, *dhln;
+    // weight-gradient GEMMs run on an internal side stream so they overlap the input-gradient chain on the
+    // caller's stream (their tails and epilogues fill each other's idle workgroup slots)
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr; hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool pending[4] = {false, false, false, false}; bool use_side = false, join_each_segment = true;
 };
 
 namespace {
@@ -258,6 +263,32 @@ int wgrad(const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW
     return kzv_gemm_tn(&a, s);
 }
 
+// buffer classes whose last side-stream reader must finish before the main stream overwrites them
+enum { CLS_DY = 0, CLS_DBIG = 1, CLS_DQKV = 2, CLS_MISC = 3 };
+
+int wgrad_async(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok,
+                int N, int K, int n_store, float* dbias) {
+    if (!m->use_side) return wgrad(dY, ldp, X, ldq, dW, Mtok, N, K, n_store, s, dbias);
+    if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess)
+        return kzv_fail(KZV_E_HIP, "wgrad_async: fork");
+    const int rc = wgrad(dY, ldp, X, ldq, dW, Mtok, N, K, n_store, m->side, dbias);
+    if (rc != KZV_OK) return rc;
+    if (hipEventRecord(m->ev_done[cls], m->side) != hipSuccess) return kzv_fail(KZV_E_HIP, "wgrad_async: record");
+    m->pending[cls] = true;
+    return KZV_OK;
+}
+int wait_cls(kzv_model* m, int cls, hipStream_t s) {
+    if (m->pending[cls]) {
+        if (hipStreamWaitEvent(s, m->ev_done[cls], 0) != hipSuccess) return kzv_fail(KZV_E_HIP, "wait_cls");
+        m->pending[cls] = false;
+    }
+    return KZV_OK;
+}
+int join_side(kzv_model* m, hipStream_t s) {
+    for (int c = 0; c < 4; ++c) KZV_TRY(wait_cls(m, c, s));
+    return KZV_OK;
+}
+
 int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, const bf16_t* K, const bf16_t* V, int64_t ldkv,
          bf16_t* O, int64_t ldo, float* LSE, const bf16_t* dO, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int heads, int Sq, int Sk,
          float drop_p, uint32_t drop_key, hipStream_t s) {
@@ -360,12 +391,12 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     float* P = m->P; float* G = m->G;
     const int CK = m->Ld * 2 * Hd;
     // ---- CE -> LM head ------------------------------------------------------------------------------
-    KZV_TRY(wgrad(m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, s, G + m->hbias));
+    KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, G + m->hbias));
     KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
     KZV_TRY(kzv_ln_bwd_ex(m->dhln, 0, m->hd_gelu, m->hd_st, P + m->hln_w, m->dsum_d, 0, G + m->hln_w, G + m->hln_b, Md, Hd, 1, 0, 0.f, 0, s));
     KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
     const bf16_t* x_last_h = m->Ld ? m->da[m->Ld - 1].x3h : m->xd0h;
-    KZV_TRY(wgrad(m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, s));
+    KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, nullptr));
     KZV_TRY(gemm(m->dy_d, Hd, m->w_hd, true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_F32, s));
     // ---- decoder layers, last to first -----------------------------------------------------------------
     for (int i = m->Ld - 1; i >= 0; --i) {
@@ -374,30 +405,36 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
         const uint32_t site = SITE_DEC_L + 8 * i;
         const bf16_t* xh = i ? m->da[i - 1].x3h : m->xd0h;
         // FFN block: x3 = LN(s3), s3 = x2 + drop(fc2(gelu(fc1(x2))))
+        KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s3, a.st3, P + d.ln3w, m->dsum_d, 0, G + d.ln3w, G + d.ln3b, Md, Hd, 1, 0, 0.f, 0, s,
                               m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 4)));
-        KZV_TRY(wgrad(m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, s, G + d.fc2b));
+        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
+        KZV_TRY(wait_cls(m, CLS_DBIG, s));
         KZV_TRY(gemm(m->dy_d, Hd, m->w_dfc2[i], true, Md, Fd, Hd, Fd, nullptr, m->dbig_d, Fd, KZV_EPI_DGELU, s, nullptr, a.pre, Fd));
-        KZV_TRY(wgrad(m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, s, G + d.fc1b));
+        KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
         KZV_TRY(gemm(m->dbig_d, Fd, m->w_dfc1[i], true, Md, Hd, Fd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // cross-attention block: x2 = LN(s2), s2 = x1 + drop(o(CA(q(x1), kv(enc))))
+        KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s2, a.st2, P + d.ln2w, m->dsum_d, 0, G + d.ln2w, G + d.ln2b, Md, Hd, 1, 0, 0.f, 0, s,
                               m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 3)));
-        KZV_TRY(wgrad(m->dy_d, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, s, G + d.cob));
+        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
+        KZV_TRY(wait_cls(m, CLS_MISC, s));   // dq_d (and, first layer, dlogits' reader) before the cross-attention backward rewrites dq_d
         KZV_TRY(gemm(m->dy_d, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
                      m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->np,
                      dp(m, c.dec_attn_dropout), key(m, site + 2), s));
-        KZV_TRY(wgrad(m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, s, G + d.cqb));
+        KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
         KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // self-attention block: x1 = LN(s1), s1 = x + drop(o(SA(qkv(x))))
+        KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s1, a.st1, P + d.ln1w, m->dsum_d, 0, G + d.ln1w, G + d.ln1b, Md, Hd, 1, 0, 0.f, 0, s,
                               m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 1)));
-        KZV_TRY(wgrad(m->dy_d, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, s, G + d.ob));
+        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
+        KZV_TRY(wait_cls(m, CLS_DQKV, s));
         KZV_TRY(gemm(m->dy_d, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
                      m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
-        KZV_TRY(wgrad(m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, s, G + d.qkvb));
+        KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
         KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
     }
     // ---- decoder embeddings: x0 = drop(LN(word + type + pos)) ---------------------------------------------
@@ -405,13 +442,14 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
                           dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
     KZV_TRY(kzv_embed_scatter_bwd(m->dsum_d, m->labels, m->L, m->posids, G + m->word, G + m->dtype, G + m->dpos, B, T, Hd, c.pad_id, s));
     // ---- cross K/V projection of all layers, encoder_decoder_proj, final encoder LN ---------------------------
-    KZV_TRY(wgrad(m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, s, G + m->ckv_b));
+    KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, G + m->ckv_b));
     KZV_TRY(gemm(m->dckv, CK, m->w_ckv, true, Mp, Hd, CK, Hd, nullptr, m->denc, Hd, KZV_EPI_BF16, s));
     if (m->has_proj) {
-        KZV_TRY(wgrad(m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, s, G + m->proj_b));
+        KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, G + m->proj_b));
         KZV_TRY(gemm(m->denc, Hd, m->w_proj, true, Mp, He, Hd, He, nullptr, m->denc_out, He, KZV_EPI_BF16, s));
     }
     // also emits the masked bf16 copy the top ViT layer's fc2 backward starts from
+    KZV_TRY(wait_cls(m, CLS_DY, s));
     KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Se, 1, 0.f, 0, s,
                           m->Le ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (m->Le - 1) + 2)));
     return KZV_OK;
@@ -425,20 +463,24 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     const EncLayerP& e = m->ep[i];
     // x_out = x_mid + drop(fc2(gelu(fc1(LN2(x_mid)))))
     // on entry dy_e = dropout-masked bf16 copy of dx_e for this layer's fc2 site (written by the LN backward above it)
-    KZV_TRY(wgrad(m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, s, G + e.fc2b));
+    KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, G + e.fc2b));
+    KZV_TRY(wait_cls(m, CLS_DBIG, s));
     KZV_TRY(gemm(m->dy_e, He, m->w_efc2[i], true, Me, Fe, He, Fe, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe));
-    KZV_TRY(wgrad(m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, s, G + e.fc1b));
+    KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
     KZV_TRY(gemm(m->dbig_e, Fe, m->w_efc1[i], true, Me, He, Fe, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(wait_cls(m, CLS_DY, s));      // dy_e is rewritten below
     KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s,
                           m->dy_e, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
     // x_mid = x_in + drop(o(attn(qkv(LN1(x_in)))))
-    KZV_TRY(wgrad(m->dy_e, He, a.ctx, He, G + e.ow, Me, He, He, He, s, G + e.ob));
+    KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.ctx, He, G + e.ow, Me, He, He, He, G + e.ob));
     KZV_TRY(gemm(m->dy_e, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(wait_cls(m, CLS_DQKV, s));    // dqkv_e is rewritten below
     KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
                  m->dqkv_e + 2 * He, c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
-    KZV_TRY(wgrad(m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, s, G + e.qkvb));
+    KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
     KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
     // ... and the masked copy for the fc2 site of the layer below (layer 0 hands fp32 dx_e to the embedding backward)
+    KZV_TRY(wait_cls(m, CLS_DY, s));
     KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_in, a.st1, P + e.ln1w, m->dx_e, 1, G + e.ln1w, G + e.ln1b, Me, He, 1, 0, 0.f, 0, s,
                           i > 0 ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (i - 1) + 2)));
     return KZV_OK;
@@ -450,7 +492,7 @@ int backward_embed(kzv_model* m, hipStream_t s) {
     float* G = m->G;
     KZV_TRY(kzv_embed_assemble_bwd(m->dx_e, m->dpatch, G + m->cls, G + m->pos, G + m->patch_b, m->B, m->np, He,
                                    dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s));
-    KZV_TRY(wgrad(m->dpatch, He, m->patches, m->PD, G + m->patch_w, Mp, He, m->PD, He, s));
+    KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dpatch, He, m->patches, m->PD, G + m->patch_w, Mp, He, m->PD, He, nullptr));
     return KZV_OK;
 }
 
@@ -482,7 +524,15 @@ extern "C" int kzv_model_create(const kzv_config* cfg, kzv_model** out) {
     return KZV_OK;
 }
 
-extern "C" int kzv_model_destroy(kzv_model* m) { delete m; return KZV_OK; }
+extern "C" int kzv_model_destroy(kzv_model* m) {
+    if (m) {
+        if (m->side) (void)hipStreamDestroy(m->side);
+        if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+        for (int i = 0; i < 4; ++i) if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
+    }
+    delete m;
+    return KZV_OK;
+}
 extern "C" int kzv_param_count(const kzv_model* m) { return m ? (int)m->table.size() : 0; }
 extern "C" int64_t kzv_param_total(const kzv_model* m) { return m ? m->total : 0; }
 
@@ -527,6 +577,16 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
     if (hipMemset(d_workspace, 0, wbytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: memset");
     if (hipMemcpy(m->d_desc, m->h_desc.data(), sizeof(KzvCastDesc) * m->ndesc, hipMemcpyHostToDevice) != hipSuccess)
         return kzv_fail(KZV_E_HIP, "model_bind: descriptor upload");
+    if (!m->side) {
+        const char* e = getenv("KZV_SIDE_STREAM");
+        m->use_side = !(e && e[0] == '0');
+        if (m->use_side) {
+            if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: side stream");
+            if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: event");
+            for (int i = 0; i < 4; ++i)
+                if (hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: event");
+        }
+    }
     m->bound = true; m->have_fwd = false;
     return KZV_OK;
 }
@@ -572,13 +632,24 @@ extern "C" int kzv_backward_segment(kzv_model* m, int seg, void* stream) {
     if (!m->have_fwd) return kzv_fail(KZV_E_STATE, "backward: call kzv_forward_loss(train=1) first");
     if (seg < 0 || seg >= m->Le + 2) return kzv_fail(KZV_E_ARG, "backward: bad segment");
     hipStream_t s = (hipStream_t)stream;
-    if (seg == 0) return backward_decoder(m, s);
-    if (seg <= m->Le) return backward_enc_layer(m, m->Le - seg, s);
-    return backward_embed(m, s);
+    int rc;
+    if (seg == 0) rc = backward_decoder(m, s);
+    else if (seg <= m->Le) rc = backward_enc_layer(m, m->Le - seg, s);
+    else rc = backward_embed(m, s);
+    if (rc != KZV_OK) return rc;
+    // contract: in `stream` order, this segment's gradient range is final -> the side stream must be joined
+    // (kzv_backward, which has no consumer between segments, joins once at the end instead)
+    if (m->join_each_segment || seg == m->Le + 1) return join_side(m, s);
+    return KZV_OK;
 }
 
 extern "C" int kzv_backward(kzv_model* m, void* stream) {
+    if (!m) return kzv_fail(KZV_E_STATE, "backward: null model");
     const int n = kzv_backward_segments(m);
-    for (int sgm = 0; sgm < n; ++sgm) KZV_TRY(kzv_backward_segment(m, sgm, stream));
-    return KZV_OK;
+    m->join_each_segment = false;
+    int rc = KZV_OK;
+    for (int sgm = 0; sgm < n && rc == KZV_OK; ++sgm) rc = kzv_backward_segment(m, sgm, stream);
+    m->join_each_segment = true;
+    if (rc != KZV_OK) (void)join_side(m, (hipStream_t)stream);
+    return rc;
 }

@@ -87,8 +87,11 @@ class Stepper:
         st = L.stream_handle()
         L.check(lib.kzv_zero_grads(m._h, st), "zero_grads")
         works = []
-        if self.world > 1:
-            import torch.distributed as dist
+        if self.world == 1:      # no consumer between segments: let the engine overlap across them
+            L.check(lib.kzv_backward(m._h, st), "backward")
+            self.opt.step(max_grad_norm=self.max_grad_norm, grad_scale=1.0)
+            return loss
+        import torch.distributed as dist
         bi = 0
         for s in range(len(self.seg_ranges)):
             L.check(lib.kzv_backward_segment(m._h, s, st), "backward_segment")
