@@ -161,6 +161,12 @@ def main():
             m2, f2, n2 = collect(kind)
             others[name] = {"ms_per_step": m2 / args.steps, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0,
                             "launches_per_step": n2 / args.steps}
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tj) and args.batch == 256 and args.dec_layers == 6:   # measured offline on this exact workload
+            k = json.load(open(tj))["kernels"].get("gemm_nt_kernel<*>")
+            if k:
+                traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
         out = {
             "metric": "line-images/sec (train)", "value": imgs / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -172,7 +178,8 @@ def main():
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> (bf16 MFMA 16x16x32, all nn.Linear fwd + dgrad)",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches_per_step": n / args.steps, "avg_launch_us": (ms / n * 1e3) if n else None,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss fetch x2-corrected + write, rocprofv3 PMC, profiles/r01_hbm_traffic.json)",
+                         "launches_per_step": n / args.steps, "avg_launch_us": (ms / n * 1e3) if n else None,
                          "kernel_ms_per_step": ms / args.steps,
                          "whole_step_TFLOP/s": step_flops / (dt / args.steps) / 1e12,
                          "whole_step_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
