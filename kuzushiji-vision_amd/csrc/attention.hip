@@ -1,10 +1,10 @@
-// Multi-head attention forward / backward for short sequences (Sq, Sk <= 192), head_dim 64, bf16 MFMA.
+// Multi-head attention forward / backward for short sequences (Sq, Sk <= 288), head_dim 64, bf16 MFMA.
 //
 // Replaces eager_attention_forward in HF ViT (modeling_vit.py:164-189: fp32 softmax, prob dropout) and the
 // RoBERTa self/cross attention (modeling_roberta.py:158-183, 186-326) with masks from :645-680 built as
 // src/models/trocr_model.py:278 does (causal AND key != pad; cross attention unmasked).
 //
-// One 256-thread workgroup per (batch, head): the head's whole K and V (<= 192 x 64 bf16 = 24 KiB each)
+// One workgroup per (batch, head): the head's whole K and V (<= 288 x 64 bf16 = 36 KiB each)
 // are staged once into LDS by LDS-DMA (XOR-swizzled 128-B rows), so HBM traffic is the algorithmic
 // minimum (Q, K, V read once, O written once).
 //
@@ -22,9 +22,9 @@
 
 namespace {
 
-constexpr int KT = 12;            // key tiles of 16 -> Sk <= 192
-constexpr int SP = KT * 16;       // padded rows of every LDS image
-constexpr int IMG = SP * 128;     // bytes of one [SP][64] bf16 image
+// Geometry is a template parameter: KT key tiles of 16 (LDS images hold SP = 16*KT rows), NW waves per workgroup.
+// (12, 4) serves Sq, Sk <= 192 (64x640 crops: 161 tokens); (18, 4 forward / 8 backward) serves <= 288 tokens
+// (the reference's default 1024x64 columns: 257 tokens).
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnP {
@@ -38,10 +38,11 @@ struct AttnP {
 };
 
 // stage `nvalid` rows (64 bf16 each, row stride ld) into a swizzled [SP][64] LDS image; rows >= nvalid are zero
+template <int SP, int NW>
 __device__ __forceinline__ void stage_image(char* img, const bf16_t* src, int64_t ld, int nvalid, const void* zero16,
                                             int w, int lane) {
     const int r8 = lane >> 3;
-    for (int pc = w; pc < SP / 8; pc += 4) {
+    for (int pc = w; pc < SP / 8; pc += NW) {
         const int row = pc * 8 + r8;
         const int chunk = (lane & 7) ^ (row & 7);
         const void* s = row < nvalid ? (const void*)(src + (int64_t)row * ld + chunk * 8) : zero16;
@@ -69,8 +70,9 @@ __device__ __forceinline__ float keep_of(const AttnP& p, unsigned e) {
 }
 
 // ================================================================================================ forward
-template <int MODE>
+template <int MODE, int KT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+    constexpr int SP = KT * 16, IMG = SP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem; char* Vs = smem + IMG;
     int* kvalid = (int*)(smem + 2 * IMG);
@@ -78,9 +80,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
     const bf16_t* Kb = p.K + (int64_t)b * p.Sk * p.ldk + h * 64;
     const bf16_t* Vb = p.V + (int64_t)b * p.Sk * p.ldv + h * 64;
-    stage_image(Ks, Kb, p.ldk, p.Sk, p.zero16, w, lane);
-    stage_image(Vs, Vb, p.ldv, p.Sk, p.zero16, w, lane);
-    if (tid < SP) kvalid[tid] = tid < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + tid] != p.pad_id);
+    stage_image<SP, 4>(Ks, Kb, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image<SP, 4>(Vs, Vb, p.ldv, p.Sk, p.zero16, w, lane);
+    for (int i = tid; i < SP; i += 256) kvalid[i] = i < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + i] != p.pad_id);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -164,33 +166,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 // LDS budget <= 80 KiB so TWO workgroups share a CU (one stages / waits at a barrier while the other computes):
 // K and V images stay resident; Q and dO come in 32-query slabs through a 2-deep ring (the slab of block qb+1
 // is in flight during block qb); dS for the current slab only.
-constexpr int DS_STRIDE = SP * 2 + 16;          // bytes per dS row (pad keeps 16-B reads conflict-light)
-constexpr int DS_BYTES = 32 * DS_STRIDE;
 constexpr int SLAB = 32 * 128;                  // 32 rows x 64 bf16
-constexpr int BWD_LDS = 2 * IMG + 4 * SLAB + DS_BYTES + 3 * SP * 4;
-static_assert(BWD_LDS <= 80 * 1024, "attention backward must fit two workgroups per CU");
+constexpr int bwd_lds_bytes(int KT) { return 2 * (KT * 16 * 128) + 4 * SLAB + 32 * (KT * 32 + 16) + 3 * KT * 16 * 4; }
+static_assert(bwd_lds_bytes(12) <= 80 * 1024, "attention backward (<= 192 tokens) must fit two workgroups per CU");
 
-// stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces, wave w issues piece w of each
+// stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces spread over the NW waves
+template <int NW>
 __device__ __forceinline__ void stage_slabs(char* qs, char* os, const bf16_t* Qb, const bf16_t* dOb, int64_t ldq, int64_t ldo,
                                             int row0, int nvalid, const void* zero16, int w, int lane) {
-    const int row = w * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (row & 7);
-    const bool ok = row0 + row < nvalid;
-    glds16_asm(ok ? (const void*)(Qb + (int64_t)(row0 + row) * ldq + chunk * 8) : zero16, qs + w * 1024);
-    glds16_asm(ok ? (const void*)(dOb + (int64_t)(row0 + row) * ldo + chunk * 8) : zero16, os + w * 1024);
+    for (int pc = w; pc < 8; pc += NW) {
+        const int pq = pc & 3;
+        const int row = pq * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        const bool ok = row0 + row < nvalid;
+        if (pc < 4) glds16_asm(ok ? (const void*)(Qb + (int64_t)(row0 + row) * ldq + chunk * 8) : zero16, qs + pq * 1024);
+        else glds16_asm(ok ? (const void*)(dOb + (int64_t)(row0 + row) * ldo + chunk * 8) : zero16, os + pq * 1024);
+    }
 }
+template <int SP, int NW>
 __device__ __forceinline__ void stage_image_asm(char* img, const bf16_t* src, int64_t ld, int nvalid, const void* zero16,
                                                 int w, int lane) {
     const int r8 = lane >> 3;
-    for (int pc = w; pc < SP / 8; pc += 4) {
+    for (int pc = w; pc < SP / 8; pc += NW) {
         const int row = pc * 8 + r8;
         const int chunk = (lane & 7) ^ (row & 7);
         glds16_asm(row < nvalid ? (const void*)(src + (int64_t)row * ld + chunk * 8) : zero16, img + pc * 1024);
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
+template <int MODE, int KT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
+    constexpr int SP = KT * 16, IMG = SP * 128, DS_STRIDE = SP * 2 + 16, DS_BYTES = 32 * DS_STRIDE;
+    constexpr int NT = NW * 64, TPW = (KT + NW - 1) / NW, TB = 8 / NW;   // threads, key tiles per wave, dQ tiles per wave
+    static_assert(TPW <= 3, "dK/dV accumulators of more than 3 key tiles per wave do not fit the register file");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem; char* Vs = smem + IMG;
     char* Qring = smem + 2 * IMG; char* Oring = Qring + 2 * SLAB;
@@ -202,16 +210,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
     const bf16_t* Qb = p.Q + (int64_t)b * p.Sq * p.ldq + h * 64;
     const bf16_t* dOb = p.dO + (int64_t)b * p.Sq * p.ldo + h * 64;
-    stage_image_asm(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
-    stage_image_asm(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
-    stage_slabs(Qring, Oring, Qb, dOb, p.ldq, p.ldo, 0, p.Sq, p.zero16, w, lane);
-    if (tid < SP) {
-        kvalid[tid] = tid < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + tid] != p.pad_id);
+    stage_image_asm<SP, NW>(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image_asm<SP, NW>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    stage_slabs<NW>(Qring, Oring, Qb, dOb, p.ldq, p.ldo, 0, p.Sq, p.zero16, w, lane);
+    for (int row = tid; row < SP; row += NT) {
+        kvalid[row] = row < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + row] != p.pad_id);
         float l = INFINITY, d = 0.f;
-        if (tid < p.Sq) {
-            l = p.LSE[((int64_t)b * p.heads + h) * p.Sq + tid];
-            const bf16_t* orow = p.O + ((int64_t)b * p.Sq + tid) * p.ldo + h * 64;
-            const bf16_t* drow = dOb + (int64_t)tid * p.ldo;
+        if (row < p.Sq) {
+            l = p.LSE[((int64_t)b * p.heads + h) * p.Sq + row];
+            const bf16_t* orow = p.O + ((int64_t)b * p.Sq + row) * p.ldo + h * 64;
+            const bf16_t* drow = dOb + (int64_t)row * p.ldo;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const bf16x8 a = *(const bf16x8*)(orow + c * 8), e = *(const bf16x8*)(drow + c * 8);
@@ -219,17 +227,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
                 for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)a[j]) * bf2f((bf16_t)e[j]);
             }
         }
-        lse[tid] = l * LOG2E; dlt[tid] = d;
+        lse[row] = l * LOG2E; dlt[row] = d;
     }
-    for (int i = tid; i < DS_BYTES / 16; i += 256) ((uint4*)dS)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
+    for (int i = tid; i < DS_BYTES / 16; i += NT) ((uint4*)dS)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nkt = (p.Sk + 15) >> 4, nqb = (p.Sq + 31) >> 5;
     const float sc = p.scale * LOG2E;
-    f32x4 dk[3][4], dv[3][4];
+    f32x4 dk[TPW][4], dv[TPW][4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int d = 0; d < 4; ++d) { dk[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
         const char* Qs = Qring + (qb & 1) * SLAB;
         const char* Os = Oring + (qb & 1) * SLAB;
         if (qb + 1 < nqb)      // next slab flies during this block's two phases
-            stage_slabs(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, p.ldq, p.ldo, (qb + 1) * 32, p.Sq, p.zero16, w, lane);
+            stage_slabs<NW>(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, p.ldq, p.ldo, (qb + 1) * 32, p.Sq, p.zero16, w, lane);
         // ---------------- phase A: per owned key tile, S / dP / P / dS for 32 queries; dV^T, dK^T ----------
         bf16x8 dOt[4], Qt[4];     // A operands shared by all key tiles of this wave: dO^T and Q^T over the slab
 #pragma unroll
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
             Qt[dt] = cat8(frag_tr(Qs, 4 * g, dt * 2, l15), frag_tr(Qs, 16 + 4 * g, dt * 2, l15));
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int kt = w + 4 * a;
+        for (int a = 0; a < TPW; ++a) {
+            const int kt = w + NW * a;
             if (kt >= nkt) continue;
             if (MODE == 1 && kt * 16 > qb * 32 + 31) {   // key tile entirely above the diagonal: dS = 0
 #pragma unroll
@@ -290,16 +298,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
         __syncthreads();
         // ---------------- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for this 32-query slab ----
         {
-            const int t2 = w >> 1;
+            const int t2 = w / (NW / 2), dt0 = (w % (NW / 2)) * TB;
             const int qloc = t2 * 16 + l15;
             const int q = qb * 32 + qloc;
-            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+            f32x4 acc[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int nks = (nkt + 1) >> 1;
             for (int ks = 0; ks < nks; ++ks) {
                 const bf16x8 dsf = *(const bf16x8*)(dS + qloc * DS_STRIDE + (ks * 32 + 8 * g) * 2);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int dt = (w & 1) * 2 + u;
+                for (int u = 0; u < TB; ++u) {
+                    const int dt = dt0 + u;
                     const bf16x8 kf = cat8(frag_tr(Ks, ks * 32 + 8 * g, dt * 2, l15), frag_tr(Ks, ks * 32 + 8 * g + 4, dt * 2, l15));
                     acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[u], 0, 0, 0);
                 }
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
             if (q < p.Sq) {
                 bf16_t* row = p.dQ + ((int64_t)b * p.Sq + q) * p.ldq + h * 64 + 4 * g;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int dt = (w & 1) * 2 + u;
+                for (int u = 0; u < TB; ++u) {
+                    const int dt = dt0 + u;
                     *(uint2*)(row + dt * 16) = make_uint2(pack_bf2(acc[u][0] * p.scale, acc[u][1] * p.scale),
                                                           pack_bf2(acc[u][2] * p.scale, acc[u][3] * p.scale));
                 }
@@ -319,9 +329,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
         __syncthreads();
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int key = (w + 4 * a) * 16 + l15;
-        if (w + 4 * a >= nkt || key >= p.Sk) continue;
+    for (int a = 0; a < TPW; ++a) {
+        const int key = (w + NW * a) * 16 + l15;
+        if (w + NW * a >= nkt || key >= p.Sk) continue;
         bf16_t* krow = p.dK + ((int64_t)b * p.Sk + key) * p.ldk + h * 64 + 4 * g;
         bf16_t* vrow = p.dV + ((int64_t)b * p.Sk + key) * p.ldv + h * 64 + 4 * g;
 #pragma unroll
@@ -335,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const AttnP p) {
 
 int fill(AttnP& p, const kzv_attn_args* a, bool bwd) {
     if (!a || !a->Q || !a->K || !a->V || !a->O) return kzv_fail(KZV_E_ARG, "attn: null operand");
-    if (a->Sq <= 0 || a->Sk <= 0 || a->Sq > SP || a->Sk > SP) return kzv_fail(KZV_E_ARG, "attn: Sq/Sk must be in 1..%d", SP);
+    if (a->Sq <= 0 || a->Sk <= 0 || a->Sq > 288 || a->Sk > 288) return kzv_fail(KZV_E_ARG, "attn: Sq/Sk must be in 1..288");
+    if (a->mode == 1 && a->Sq > 192) return kzv_fail(KZV_E_ARG, "attn: causal mode is built for <= 192 tokens");
     if (a->mode == 1 && (!a->ids || a->Sq != a->Sk)) return kzv_fail(KZV_E_ARG, "attn: causal mode needs ids and Sq == Sk");
     if (a->mode != 0 && a->mode != 1) return kzv_fail(KZV_E_ARG, "attn: unknown mode");
     if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8) return kzv_fail(KZV_E_ARG, "attn: row strides must be multiples of 8");
@@ -358,11 +369,16 @@ int fill(AttnP& p, const kzv_attn_args* a, bool bwd) {
 extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
     AttnP p;
     if (int rc = fill(p, a, false)) return rc;
-    const int lds = 2 * IMG + SP * 4;
     hipStream_t s = (hipStream_t)stream;
+    const bool big = a->Sq > 192 || a->Sk > 192;
+    const int lds = big ? 2 * (288 * 128) + 288 * 4 : 2 * (192 * 128) + 192 * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<0, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (288 * 128) + 288 * 4); attr = true; }
     KzvProfScope prof(2, 4.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
-    if (a->mode == 0) hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(a->B * a->heads), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(a->B * a->heads), dim3(256), lds, s, p);
+    const dim3 grid(a->B * a->heads);
+    if (a->mode == 1) hipLaunchKernelGGL((attn_fwd_kernel<1, 12>), grid, dim3(256), lds, s, p);
+    else if (big) hipLaunchKernelGGL((attn_fwd_kernel<0, 18>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<0, 12>), grid, dim3(256), lds, s, p);
     return kzv_check_launch("attn_fwd");
 }
 
@@ -372,12 +388,16 @@ extern "C" int kzv_attn_bwd(const kzv_attn_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(12));
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(12));
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0, 18, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(18));
         attr = true;
     }
+    const bool big = a->Sq > 192 || a->Sk > 192;
     KzvProfScope prof(3, 10.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
-    if (a->mode == 0) hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(a->B * a->heads), dim3(256), BWD_LDS, s, p);
-    else hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(a->B * a->heads), dim3(256), BWD_LDS, s, p);
+    const dim3 grid(a->B * a->heads);
+    if (a->mode == 1) hipLaunchKernelGGL((attn_bwd_kernel<1, 12, 4>), grid, dim3(256), bwd_lds_bytes(12), s, p);
+    else if (big) hipLaunchKernelGGL((attn_bwd_kernel<0, 18, 8>), grid, dim3(512), bwd_lds_bytes(18), s, p);
+    else hipLaunchKernelGGL((attn_bwd_kernel<0, 12, 4>), grid, dim3(256), bwd_lds_bytes(12), s, p);
     return kzv_check_launch("attn_bwd");
 }

@@ -509,7 +509,7 @@ extern "C" int kzv_model_create(const kzv_config* cfg, kzv_model** out) {
     if (c.enc_ffn % 64 || c.dec_ffn % 64 || (c.channels * c.patch_h * c.patch_w) % 64 || c.patch_w % 8)
         return kzv_fail(KZV_E_ARG, "model_create: ffn sizes and C*ph*pw must be multiples of 64, patch_w of 8");
     const int np = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);
-    if (np + 1 > 192) return kzv_fail(KZV_E_ARG, "model_create: %d patches + CLS exceed the 192-token attention kernels", np);
+    if (np + 1 > 288) return kzv_fail(KZV_E_ARG, "model_create: %d patches + CLS exceed the 288-token attention kernels", np);
     if (c.vocab < 8 || c.max_pos < 4 || c.type_vocab < 1 || c.pad_id < 0 || c.pad_id >= c.vocab)
         return kzv_fail(KZV_E_ARG, "model_create: bad vocabulary geometry");
     if (c.enc_layers < 0 || c.dec_layers < 0) return kzv_fail(KZV_E_ARG, "model_create: negative layer count");

@@ -161,3 +161,35 @@ def test_training_step_with_dropout_reduces_loss(tmp_path):
     opt.train()
     assert np.isfinite(v)
     assert (m.flat_params - before).abs().max().item() < 1e-5
+
+
+def test_reference_default_geometry_1024x64_columns(tmp_path):
+    """The reference's default image size (scripts/train_trocr.py:39: 1024x64 -> 256 patches + CLS = 257 tokens)
+    runs through the > 192-token attention kernels; forward/loss and gradients vs the CPU oracle."""
+    import dataclasses
+    cfg = dataclasses.replace(_no_dropout(tiny_config()), image_h=1024, image_w=64)
+    m = _make(cfg, tmp_path, 11)
+    m.train()
+    px, lab = synthetic_batch(cfg, 2, 20, seed=4, min_chars=3, max_chars=19)
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    m.backward()
+    torch.cuda.synchronize()
+    r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 11)), px, lab)
+    assert np.abs(out["logits"].cpu().numpy() - r["logits"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - r["loss"]) < 5e-3
+    grads = m.grad_dict()
+    for name in ("encoder.encoder.layer.0.attention.attention.query.weight", "encoder.encoder.layer.1.output.dense.weight",
+                 "encoder.position_embeddings", "encoder.patch_embeddings.projection.weight",
+                 "decoder.roberta.encoder.layer.0.crossattention.self.key.weight"):
+        want = r["grads"][name]
+        got = grads[name].cpu().numpy().reshape(want.shape)
+        assert np.abs(got - want).max() < 0.05 * np.abs(want).max() + 1e-7, name
+
+
+def test_too_many_tokens_is_rejected(tmp_path):
+    import dataclasses
+    cfg = dataclasses.replace(tiny_config(), image_h=1024, image_w=80)   # 64 x 5 = 320 patches
+    d = build_decoder_dir(str(tmp_path / "dec"), cfg)
+    from kzv._lib import KzvError
+    with pytest.raises(KzvError, match="288-token"):
+        TrOCRModel(cfg.encoder_config_dict(), d, load_tokenizer=False)

@@ -148,7 +148,10 @@ def _attn_ref(q, k, v, heads, mask):
 
 
 @pytest.mark.parametrize("B,heads,Sq,Sk,mode", [(2, 2, 9, 9, 0), (3, 12, 161, 161, 0), (2, 4, 127, 160, 0),
-                                                (3, 4, 127, 127, 1), (2, 1, 23, 23, 1), (1, 3, 192, 192, 0)])
+                                                (3, 4, 127, 127, 1), (2, 1, 23, 23, 1), (1, 3, 192, 192, 0),
+                                                # > 192 tokens: the reference's default 1024x64 columns (257 tokens),
+                                                # cross attention over 256 patches, and the 288-token maximum
+                                                (2, 3, 257, 257, 0), (2, 4, 127, 256, 0), (1, 2, 288, 288, 0), (1, 1, 193, 40, 0)])
 def test_attention_fwd_bwd(lib, B, heads, Sq, Sk, mode):
     torch.manual_seed(Sq * 7 + Sk)
     H = heads * 64
