@@ -72,6 +72,12 @@ int kzv_model_sync_weights(kzv_model* m, void* stream);
 int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels,
                      float* d_loss, float* d_logits, int train, uint64_t seed, void* stream);
 
+/* Decoder-only teacher-forced pass over `d_labels` [B,L] reusing the encoder states (and cross-attention K/V) of the
+ * last kzv_forward_loss on this handle; writes the logits of position `pos` of every sample, fp32 [B,V].  Building
+ * block of generation (TrOCRModel.forward inference branch, trocr_model.py:298-321): under the causal mask position
+ * pos only depends on ids[:, :pos+1].  Invalidates the saved activations (no backward afterwards). */
+int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos, float* d_logits, void* stream);
+
 /* loss.backward() for the step above: fills the bound fp32 grad buffer (which must be zero on entry;
  * kzv_zero_grads does that).  Backward is split in `kzv_backward_segments()` segments so the host can
  * launch an RCCL all-reduce for a segment's finished gradients while later segments still run

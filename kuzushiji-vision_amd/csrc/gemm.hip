@@ -437,13 +437,11 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
         KZV_NT_CASE(KZV_EPI_DGELU, WM, WN, NS, KB, AD) KZV_NT_CASE(KZV_EPI_GELU_F32, WM, WN, NS, KB, AD)  \
         default: return kzv_fail(KZV_E_ARG, "gemm_nt: unknown epilogue");                                 \
     }
-    switch (kzv_nt_variant()) {
-        case 1: KZV_NT_VARIANT(2, 2, 2, 32, false) break;
-        case 2: KZV_NT_VARIANT(2, 2, 3, 32, true) break;
-        case 3: KZV_NT_VARIANT(2, 2, 4, 32, true) break;
-        case 4: KZV_NT_VARIANT(2, 2, 2, 64, true) break;
-        default: KZV_NT_VARIANT(2, 2, 2, 64, false) break;
-    }
+    // Measured on MI355X (tools/dev/gemm_bench.py, round 1): 128x128x64 / 2-stage ring / 2 workgroups per CU is the
+    // fastest of the variants this template expresses (KB = 32 with 2-4 stages: -5..-15 %; 256x128 tiles at one
+    // workgroup per CU: -3 %; a 3-stage ring at one workgroup per CU: -30 %), so only it is instantiated.
+    (void)kzv_nt_variant;
+    KZV_NT_VARIANT(2, 2, 2, 64, false)
 #undef KZV_NT_VARIANT
 #undef KZV_NT_CASE
     return kzv_check_launch("gemm_nt");

@@ -51,7 +51,7 @@ struct kzv_model {
     // bound state
     float* P = nullptr; float* G = nullptr; char* ws = nullptr; int64_t ws_bytes = 0;
     int B = 0, L = 0, T = 0;
-    bool bound = false, have_fwd = false, train = false;
+    bool bound = false, have_fwd = false, have_enc = false, train = false;
     uint64_t seed = 0;
     const int64_t* labels = nullptr;
     // workspace pointers
@@ -302,7 +302,8 @@ int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, c
 }
 
 // ================================================================================================ forward
-int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss, float* d_logits, hipStream_t s) {
+int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss, float* d_logits, hipStream_t s,
+            bool run_encoder = true, int logits_pos = -1) {
     const kzv_config& c = m->c;
     const int B = m->B, T = m->T, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
     const int Me = B * m->Se, Mp = B * m->np, Md = B * T;
@@ -310,6 +311,8 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     const float eps = c.ln_eps;
     m->labels = labels;
     if (hipMemsetAsync(m->count, 0, 64 * sizeof(float), s) != hipSuccess) return kzv_fail(KZV_E_HIP, "forward: memset");
+    const int CK = m->Ld * 2 * Hd;
+    if (run_encoder) {
     // ---- patch embedding: Conv2d(k=s=16) == im2row + GEMM (trocr_model.py:77,89-90) -----------------
     KZV_TRY(kzv_im2row(px, m->patches, B, c.channels, c.image_h, c.image_w, c.patch_h, c.patch_w, s));
     KZV_TRY(gemm(m->patches, m->PD, m->w_patch, false, Mp, He, m->PD, He, P + m->patch_b, m->pe32, He, KZV_EPI_F32, s));
@@ -336,8 +339,9 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     if (m->has_proj)
         KZV_TRY(gemm(m->enc_out, He, m->w_proj, false, Mp, Hd, He, Hd, P + m->proj_b, m->proj_out, Hd, KZV_EPI_BF16, s));
     // cross-attention K/V of every decoder layer in one GEMM
-    const int CK = m->Ld * 2 * Hd;
     KZV_TRY(gemm(m->proj_out, Hd, m->w_ckv, false, Mp, CK, Hd, CK, P + m->ckv_b, m->crosskv, CK, KZV_EPI_BF16, s));
+    m->have_enc = true;
+    }   // run_encoder
     // ---- decoder embeddings (HF modeling_roberta.py:75-122,142-155) --------------------------------------
     KZV_TRY(kzv_dec_prepare(labels, B, m->L, c.pad_id, c.max_pos, m->posids, m->count, m->err, s));
     KZV_TRY(kzv_embed_gather(labels, m->L, m->posids, P + m->word, P + m->dtype, P + m->dpos, m->emb_sum, B, T, Hd, s));
@@ -374,7 +378,9 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     KZV_TRY(kzv_ce_fwd_bwd(m->logits, m->Vp, labels, m->L, B, T, m->V, c.pad_id, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, s));
     if (d_loss && hipMemcpyAsync(d_loss, m->loss_acc, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return kzv_fail(KZV_E_HIP, "forward: loss copy");
-    if (d_logits) KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, Md, m->V, s));
+    if (d_logits && logits_pos < 0) KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, Md, m->V, s));
+    if (d_logits && logits_pos >= 0)   // one position of every sample: rows b*T + pos
+        KZV_TRY(kzv_copy_logits(m->logits + (int64_t)logits_pos * m->Vp, (int64_t)T * m->Vp, d_logits, B, m->V, s));
     return KZV_OK;
 }
 
@@ -589,7 +595,7 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
                 if (hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: event");
         }
     }
-    m->bound = true; m->have_fwd = false;
+    m->bound = true; m->have_fwd = false; m->have_enc = false;
     return KZV_OK;
 }
 
@@ -606,6 +612,15 @@ extern "C" int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const
     const int rc = forward(m, d_pixel_values, d_labels, d_loss, d_logits, (hipStream_t)stream);
     m->have_fwd = rc == KZV_OK && m->train;
     return rc;
+}
+
+extern "C" int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos, float* d_logits, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_logits: model not bound");
+    if (!m->have_enc) return kzv_fail(KZV_E_STATE, "decode_logits: call kzv_forward_loss on the images first");
+    if (!d_labels || !d_logits || pos < 0 || pos >= m->T) return kzv_fail(KZV_E_ARG, "decode_logits: bad argument");
+    m->train = false;
+    m->have_fwd = false;     // decoder activations are overwritten: no backward after this
+    return forward(m, nullptr, d_labels, nullptr, d_logits, (hipStream_t)stream, false, pos);
 }
 
 extern "C" int kzv_zero_grads(kzv_model* m, void* stream) {

@@ -222,23 +222,27 @@ class TrOCRModel:
         L.check(lib.kzv_backward(self._h, st), "kzv_backward")
 
     def generate(self, pixel_values, max_length: int = 128):
-        """Greedy decode from BOS by repeated teacher-forced forwards (each position's logits only depend on
-        earlier ids under the causal mask).  The reference calls HF beam-4 ``generate`` (trocr_model.py:306-316);
-        beam search + KV cache is the N1 "next" row of SURVEY.md section 8(f) -- see DESIGN.md."""
+        """Greedy decode from BOS.  The encoder (and the cross-attention K/V of every decoder layer) runs ONCE; each
+        step is a decoder-only teacher-forced pass (kzv_decode_logits) whose position-t logits only depend on
+        ids[:, :t+1] under the causal mask.  The reference calls HF beam-4 ``generate`` (trocr_model.py:306-316);
+        beam search + a KV cache is the N1 "next" row of SURVEY.md section 8(f) -- see DESIGN.md."""
         import torch
         c = self.cfg
         px = self._check_inputs(pixel_values)
         B = px.shape[0]
         Lh = min(max_length, c.max_pos - c.pad_id - 1)
+        lib = L.load()
         was = self.training
         self.training = False
         ids = torch.full((B, Lh), c.pad_id, dtype=torch.int64, device=self.device)
         ids[:, 0] = c.bos_id
         done = torch.zeros(B, dtype=torch.bool, device=self.device)
+        step_logits = torch.empty(B, c.vocab, dtype=torch.float32, device=self.device)
+        self.forward_loss(px, ids, want_logits=False, seed=0)          # encoder + first decoder pass
         n = 1
         for t in range(Lh - 1):
-            _, logits = self.forward_loss(px, ids, want_logits=True, seed=0)
-            nxt = logits[:, t].argmax(-1)
+            L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
+            nxt = step_logits.argmax(-1)
             nxt = torch.where(done, torch.full_like(nxt, c.pad_id), nxt)
             ids[:, t + 1] = nxt
             n = t + 2
