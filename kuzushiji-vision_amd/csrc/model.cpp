@@ -518,7 +518,7 @@ extern "C" int kzv_model_create(const kzv_config* cfg, kzv_model** out) {
     if (np + 1 > 288) return kzv_fail(KZV_E_ARG, "model_create: %d patches + CLS exceed the 288-token attention kernels", np);
     if (c.vocab < 8 || c.max_pos < 4 || c.type_vocab < 1 || c.pad_id < 0 || c.pad_id >= c.vocab)
         return kzv_fail(KZV_E_ARG, "model_create: bad vocabulary geometry");
-    if (c.enc_layers < 0 || c.dec_layers < 0) return kzv_fail(KZV_E_ARG, "model_create: negative layer count");
+    if (c.enc_layers < 1 || c.dec_layers < 1) return kzv_fail(KZV_E_ARG, "model_create: encoder and decoder need at least one layer each");
     kzv_model* m = new kzv_model();
     m->c = c;
     m->np = np; m->Se = np + 1; m->PD = c.channels * c.patch_h * c.patch_w;

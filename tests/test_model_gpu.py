@@ -240,3 +240,40 @@ def test_generate_is_consistent_and_overfit_model_reproduces_labels(tmp_path):
         return "".join(chars[t - 5] for t in ids if t >= 5)
     cers = [m.calculate_cer(text(gen[b]), text(lab[b])) for b in range(4)]
     assert cers == [0.0, 0.0, 0.0, 0.0], cers
+
+
+@pytest.mark.parametrize("B,L,kw", [
+    (1, 2, {}),                                              # one decoder position
+    (7, 5, {}), (3, 39, {}),                                 # ragged M (not a multiple of any tile), max_pos - 1 labels
+    (5, 17, dict(enc_hidden=64, enc_heads=1, dec_hidden=64)),  # encoder_decoder_proj is nn.Identity (trocr_model.py:250-253)
+    (2, 12, dict(image_h=16, image_w=16)),                   # a single patch (+ CLS)
+    (2, 12, dict(enc_layers=1, dec_layers=1)),
+    (300, 9, {}),                                            # batch larger than the bench's
+])
+def test_edge_geometries_match_oracle(tmp_path, B, L, kw):
+    import dataclasses
+    cfg = dataclasses.replace(_no_dropout(tiny_config()), **kw)
+    m = _make(cfg, tmp_path, 3)
+    px, lab = synthetic_batch(cfg, B, L, seed=B, min_chars=1, max_chars=L)
+    m.train()
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    m.backward()
+    torch.cuda.synchronize()
+    r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 3)), px, lab)
+    assert np.abs(out["logits"].cpu().numpy() - r["logits"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - r["loss"]) < 5e-3
+    g = m.grad_dict()
+    for k, v in r["grads"].items():
+        if v is None or k.endswith("key.bias"):
+            continue
+        got = g[k].cpu().numpy().reshape(v.shape)
+        assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, k
+
+
+def test_zero_layer_models_are_rejected(tmp_path):
+    import dataclasses
+    from kzv._lib import KzvError
+    cfg = dataclasses.replace(tiny_config(), dec_layers=0)
+    d = build_decoder_dir(str(tmp_path / "dec"), cfg)
+    with pytest.raises(KzvError, match="at least one layer"):
+        TrOCRModel(cfg.encoder_config_dict(), d, load_tokenizer=False)
