@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
-                    const bool ok = kvalid[key] && (MODE == 0 || key <= q);
+                    const bool ok = MODE == 0 ? key < p.Sk : (kvalid[key] && key <= q);
                     s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
                     mx = fmaxf(mx, s[kt][r]);
                 }
@@ -128,16 +128,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
         const float inv = dead ? 0.f : 1.f / sum;
         if (p.LSE && g == 0 && q < p.Sq)
             p.LSE[((int64_t)b * p.heads + h) * p.Sq + q] = dead ? INFINITY : (mx + log2f(sum)) * (1.f / LOG2E);
-        const unsigned ebase = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)p.Sk;
+        // dropout element index = (row of P) * Sk_even + key: the row base is even, so this lane's 4 consecutive keys
+        // are exactly two hash pairs (2 hashes per 4 probabilities instead of 4)
+        const unsigned ebase = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
             if (kt < nk) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kt][r] * inv;
-                    if (p.thr16) v *= keep_of(p, ebase + kt * 16 + 4 * g + r);
-                    s[kt][r] = v;
+                float k4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.thr16) {
+                    const unsigned pr = (ebase + kt * 16 + 4 * g) >> 1;
+                    const unsigned b0 = drop_bits(p.key, pr), b1 = drop_bits(p.key, pr + 1);
+                    k4[0] = drop_keep(b0, 0, p.thr16, p.inv_keep); k4[1] = drop_keep(b0, 1, p.thr16, p.inv_keep);
+                    k4[2] = drop_keep(b1, 0, p.thr16, p.inv_keep); k4[3] = drop_keep(b1, 1, p.thr16, p.inv_keep);
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * k4[r];
             }
         f32x4 o[4];
 #pragma unroll
@@ -253,6 +258,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
             dOt[dt] = cat8(frag_tr(Os, 4 * g, dt * 2, l15), frag_tr(Os, 16 + 4 * g, dt * 2, l15));
             Qt[dt] = cat8(frag_tr(Qs, 4 * g, dt * 2, l15), frag_tr(Qs, 16 + 4 * g, dt * 2, l15));
         }
+        float lq[8], dq8[8];      // log-sum-exp and delta of this lane's 8 query rows: read once per slab, not per key tile
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int q = qb * 32 + (r >> 2) * 16 + 4 * g + (r & 3);
+            lq[r] = lse[q]; dq8[r] = dlt[q];
+        }
 #pragma unroll
         for (int a = 0; a < TPW; ++a) {
             const int kt = w + NW * a;
@@ -280,11 +291,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
                 for (int r = 0; r < 4; ++r) {
                     const int q = qb * 32 + t2 * 16 + 4 * g + r;
                     const bool ok = kok && (MODE == 0 || key <= q);
-                    float pr = ok ? __builtin_amdgcn_exp2f(S[r] * sc - lse[q]) : 0.f;      // lse = +inf for q >= Sq / dead rows
+                    float pr = ok ? __builtin_amdgcn_exp2f(S[r] * sc - lq[t2 * 4 + r]) : 0.f;      // lse = +inf for q >= Sq / dead rows
                     float kp = 1.f;
-                    if (p.thr16) kp = keep_of(p, (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)p.Sk + key);
+                    if (p.thr16) kp = keep_of(p, (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1) + key);
                     pd[t2 * 4 + r] = pr * kp;
-                    ds[t2 * 4 + r] = pr * (dP[r] * kp - dlt[q]);
+                    ds[t2 * 4 + r] = pr * (dP[r] * kp - dq8[t2 * 4 + r]);
                     *(bf16_t*)(dS + (t2 * 16 + 4 * g + r) * DS_STRIDE + key * 2) = f2bf(ds[t2 * 4 + r]);
                 }
             }

@@ -277,3 +277,22 @@ def test_zero_layer_models_are_rejected(tmp_path):
     d = build_decoder_dir(str(tmp_path / "dec"), cfg)
     with pytest.raises(KzvError, match="at least one layer"):
         TrOCRModel(cfg.encoder_config_dict(), d, load_tokenizer=False)
+
+
+def test_train_cli_two_epochs_synthetic_writes_checkpoints(tmp_path):
+    """The reference's integration-test idiom (tests/test_train_script.py:55-108: run the CLI briefly, expect
+    a checkpoint) on BASELINE.json configs[0]-style plumbing: small encoder, synthetic crops, 1 GPU."""
+    from kzv.train import main
+    from kzv.trainer import load_checkpoint
+    hist = main(["--synthetic", "16", "--batch_size", "8", "--encoder_hidden_size", "128", "--encoder_num_layers", "2",
+                 "--encoder_num_heads", "2", "--image_size", "32", "64", "--max_length", "16", "--max_epochs", "2",
+                 "--output_dir", str(tmp_path), "--experiment_name", "t"])
+    assert hist and all(np.isfinite(v) for _, v in hist)
+    ck = tmp_path / "t" / "checkpoints"
+    names = sorted(p.name for p in ck.iterdir())
+    assert "last.ckpt" in names and any(n.startswith("trocr-epoch=") for n in names)
+    # checkpoint round trip through the HF-named state_dict
+    import torch
+    sd = torch.load(ck / "last.ckpt", map_location="cpu", weights_only=False)
+    assert "encoder.patch_embeddings.projection.weight" in sd["state_dict"]
+    assert sd["optimizer_states"][0]["k"] == 4       # 2 epochs x 2 steps
