@@ -53,6 +53,7 @@ def parse_args(argv=None):
     p.add_argument("--accelerator", type=str, default="gpu")
     p.add_argument("--precision", type=str, default="bf16-mixed", choices=["16-mixed", "32", "bf16-mixed"])
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--ema_decay", type=float, default=0.0, help="> 0 attaches kzv.ema.EMACallback (reference: decay 0.9999)")
     return p.parse_args(argv)
 
 
@@ -106,8 +107,13 @@ def main(argv=None):
     val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world)
     if rank == 0:
         print(f"Train samples: {len(train_ds)}\nVal samples: {len(val_ds)}\nParameters: {model.num_parameters():,}")
+    cbs = []
+    if args.ema_decay > 0:
+        from .ema import EMACallback
+        cbs.append(EMACallback(args.ema_decay))
     hist = fit(model, train_loader, val_loader, max_epochs=args.max_epochs, max_steps=args.max_steps, log_every=50,
-               val_check_interval=0.5, ckpt_dir=os.path.join(out_dir, "checkpoints"), world=world, rank=rank)
+               val_check_interval=0.5, ckpt_dir=os.path.join(out_dir, "checkpoints"), world=world, rank=rank,
+               callbacks=cbs)
     if rank == 0:
         print(f"Training completed! Checkpoints saved to: {os.path.join(out_dir, 'checkpoints')}")
     if world > 1:

@@ -108,12 +108,15 @@ class Stepper:
 
 
 def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: int = -1, log_every: int = 50,
-        val_check_interval: float = 0.5, ckpt_dir: str | None = None, world: int = 1, rank: int = 0, log=print):
+        val_check_interval: float = 0.5, ckpt_dir: str | None = None, world: int = 1, rank: int = 0, log=print,
+        callbacks=()):
     """Minimal Trainer.fit: epochs over the loader, validation every ``val_check_interval`` of an epoch
     (scripts/train_trocr.py:174), rank-0 checkpoints named like the reference (:138)."""
     import torch
     opt = model.configure_optimizers()
     stepper = Stepper(model, opt, world=world)
+    for cb in callbacks:          # e.g. kzv.ema.EMACallback (scripts/train_trocr.py:154,182)
+        cb.on_fit_start(model)
     gstep = 0
     history = []
     n_batches = len(train_loader)
@@ -125,6 +128,8 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
         for i, batch in enumerate(train_loader):
             loss = stepper.step(batch, i)
             gstep += 1
+            for cb in callbacks:
+                cb.on_train_batch_end(model)
             if gstep % log_every == 0 or gstep == 1:
                 lv = float(loss.item())
                 history.append((gstep, lv))
@@ -132,7 +137,11 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
                     log(f"epoch {epoch} step {gstep} train_loss {lv:.4f} lr {opt.scheduled_lr:.3g}")
             if val_every and (i + 1) % val_every == 0:
                 model.on_validation_epoch_start()
+                for cb in callbacks:
+                    cb.on_validation_start(model)
                 vals = [model.validation_step(vb, j) for j, vb in enumerate(val_loader)]
+                for cb in callbacks:
+                    cb.on_validation_end(model)
                 model.on_validation_epoch_end()
                 model.train()
                 vl = sum(vals) / max(1, len(vals))
@@ -140,7 +149,7 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
                     log(f"epoch {epoch} step {gstep} val_loss {vl:.4f}")
                     if ckpt_dir:
                         os.makedirs(ckpt_dir, exist_ok=True)
-                        save_checkpoint(model, opt, os.path.join(ckpt_dir, f"trocr-epoch={epoch:02d}-val_loss={vl:.2f}.ckpt"), epoch, gstep)
+                        save_checkpoint(model, opt, os.path.join(ckpt_dir, f"trocr-epoch={epoch:02d}-val_loss={vl:.2f}.ckpt"), epoch, gstep, callbacks)
             if 0 < max_steps <= gstep:
                 break
         torch.cuda.synchronize()
@@ -150,15 +159,18 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
             break
     if ckpt_dir and rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
-        save_checkpoint(model, opt, os.path.join(ckpt_dir, "last.ckpt"), max_epochs - 1, gstep)
+        save_checkpoint(model, opt, os.path.join(ckpt_dir, "last.ckpt"), max_epochs - 1, gstep, callbacks)
     return history
 
 
-def save_checkpoint(model, opt, path: str, epoch: int, global_step: int) -> None:
+def save_checkpoint(model, opt, path: str, epoch: int, global_step: int, callbacks=()) -> None:
     """Lightning-shaped dict: state_dict under HF names + hyper-parameters + optimizer state."""
     import torch
-    torch.save({"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
-                "hyper_parameters": vars(model.hparams), "optimizer_states": [opt.state_dict()]}, path)
+    ck = {"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
+          "hyper_parameters": vars(model.hparams), "optimizer_states": [opt.state_dict()]}
+    for cb in callbacks:
+        ck = cb.on_save_checkpoint(model, ck)
+    torch.save(ck, path)
 
 
 def load_checkpoint(model, opt, path: str):

@@ -296,3 +296,38 @@ def test_train_cli_two_epochs_synthetic_writes_checkpoints(tmp_path):
     sd = torch.load(ck / "last.ckpt", map_location="cpu", weights_only=False)
     assert "encoder.patch_embeddings.projection.weight" in sd["state_dict"]
     assert sd["optimizer_states"][0]["k"] == 4       # 2 epochs x 2 steps
+
+
+def test_ema_callback_matches_reference_update_rule(tmp_path):
+    """src/callbacks/ema.py:51-58,60-73: shadow.mul_(decay).add_(param, alpha=1-decay); swap for validation; restore."""
+    from kzv.ema import EMACallback
+    cfg = tiny_config()
+    m = _make(cfg, tmp_path, 2)
+    opt = m.configure_optimizers()
+    opt.lr = 1e-2
+    ema = EMACallback(decay=0.9)
+    ema.on_fit_start(m)
+    px, lab = synthetic_batch(cfg, 4, 12, seed=1, min_chars=2, max_chars=11)
+    batch = {"pixel_values": torch.from_numpy(px), "labels": torch.from_numpy(lab)}
+    ref = m.flat_params.clone()
+    m.train()
+    for i in range(8):
+        m.training_step(batch, i)
+        opt.step(max_grad_norm=1.0)
+        ema.on_train_batch_end(m)
+        ref.mul_(0.9).add_(m.flat_params, alpha=0.1)
+    assert (ema.shadow - ref).abs().max().item() < 1e-6
+    assert (ema.shadow - m.flat_params).abs().max().item() > 1e-5        # the average lags the parameters
+    live = m.flat_params.clone()
+    ema.on_validation_start(m)
+    assert torch.equal(m.flat_params, ema.shadow)
+    v = m.validation_step(batch, 99)
+    ema.on_validation_end(m)
+    assert torch.equal(m.flat_params, live) and np.isfinite(v)
+    ck = ema.on_save_checkpoint(m, {})
+    assert "encoder.cls_token" in ck["ema_shadow"]
+    ema2 = EMACallback(decay=0.9)
+    ema2.on_load_checkpoint(m, ck)
+    assert torch.equal(ema2.shadow, ema.shadow)
+    with pytest.raises(ValueError):
+        EMACallback(decay=1.5)
