@@ -212,7 +212,8 @@ class TrOCRModel:
         if labels is not None:
             loss, logits = self.forward_loss(pixel_values, labels, want_logits=True)
             return {"logits": logits, "loss": loss.clone().reshape(())}
-        return {"generated_ids": self.generate(pixel_values), "logits": None}
+        # trocr_model.py:306-316: max_length=128, num_beams=4, early_stopping=True
+        return {"generated_ids": self.generate(pixel_values, max_length=128, num_beams=4, early_stopping=True), "logits": None}
 
     def backward(self) -> None:
         """loss.backward() of the last training-mode forward: fills flat_grads (zeroed first)."""
@@ -221,11 +222,17 @@ class TrOCRModel:
         L.check(lib.kzv_zero_grads(self._h, st), "zero_grads")
         L.check(lib.kzv_backward(self._h, st), "kzv_backward")
 
-    def generate(self, pixel_values, max_length: int = 128):
-        """Greedy decode from BOS.  The encoder (and the cross-attention K/V of every decoder layer) runs ONCE; each
-        step is a decoder-only teacher-forced pass (kzv_decode_logits) whose position-t logits only depend on
-        ids[:, :t+1] under the causal mask.  The reference calls HF beam-4 ``generate`` (trocr_model.py:306-316);
-        beam search + a KV cache is the N1 "next" row of SURVEY.md section 8(f) -- see DESIGN.md."""
+    def generate(self, pixel_values, max_length: int = 128, num_beams: int = 1, early_stopping: bool = True,
+                 length_penalty: float = 1.0):
+        """Decode from BOS.  The encoder (and the cross-attention K/V of every decoder layer) runs ONCE; each step is a
+        decoder-only teacher-forced pass (kzv_decode_logits) whose position-t logits only depend on ids[:, :t+1] under
+        the causal mask -- no KV cache, so re-ordering beams is a row gather of the id buffer.
+
+        num_beams == 1: greedy.  num_beams > 1: beam search with HF's bookkeeping (2*num_beams candidates per step, EOS
+        candidates ranked >= num_beams dropped, hypothesis score = sum log-prob / len**length_penalty, early stopping once
+        num_beams hypotheses are finished) -- what the reference asks of ``decoder.generate(num_beams=4,
+        early_stopping=True)`` (trocr_model.py:306-316).  Parity with HF's implementation is UNPINNED.
+        The beam bookkeeping (top-k, log-softmax over [B*beams, V]) is host-side torch glue, like HF's own Python."""
         import torch
         c = self.cfg
         px = self._check_inputs(pixel_values)
@@ -234,23 +241,86 @@ class TrOCRModel:
         lib = L.load()
         was = self.training
         self.training = False
-        ids = torch.full((B, Lh), c.pad_id, dtype=torch.int64, device=self.device)
+        nb = max(1, int(num_beams))
+        if nb > 1:
+            px = px.repeat_interleave(nb, dim=0)
+        BB = B * nb
+        ids = torch.full((BB, Lh), c.pad_id, dtype=torch.int64, device=self.device)
         ids[:, 0] = c.bos_id
-        done = torch.zeros(B, dtype=torch.bool, device=self.device)
-        step_logits = torch.empty(B, c.vocab, dtype=torch.float32, device=self.device)
+        step_logits = torch.empty(BB, c.vocab, dtype=torch.float32, device=self.device)
         self.forward_loss(px, ids, want_logits=False, seed=0)          # encoder + first decoder pass
-        n = 1
-        for t in range(Lh - 1):
+
+        def logits_at(t):
             L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
-            nxt = step_logits.argmax(-1)
-            nxt = torch.where(done, torch.full_like(nxt, c.pad_id), nxt)
-            ids[:, t + 1] = nxt
-            n = t + 2
-            done |= nxt == c.eos_id
-            if bool(done.all()):
+            return step_logits
+
+        if nb == 1:
+            done = torch.zeros(B, dtype=torch.bool, device=self.device)
+            n = 1
+            for t in range(Lh - 1):
+                nxt = logits_at(t).argmax(-1)
+                nxt = torch.where(done, torch.full_like(nxt, c.pad_id), nxt)
+                ids[:, t + 1] = nxt
+                n = t + 2
+                done |= nxt == c.eos_id
+                if bool(done.all()):
+                    break
+            self.training = was
+            return ids[:, :n]
+
+        beam_scores = torch.zeros(B, nb, device=self.device)
+        beam_scores[:, 1:] = -1e9
+        hyps = [[] for _ in range(B)]                  # (score, token list)
+        done = [False] * B
+        cur = 1
+        for t in range(Lh - 1):
+            lp = torch.log_softmax(logits_at(t), dim=-1) + beam_scores.view(-1, 1)
+            top_s, top_i = lp.view(B, nb * c.vocab).topk(2 * nb, dim=1)
+            top_s, top_i = top_s.cpu(), top_i.cpu()
+            ids_cpu = ids[:, :cur].cpu()
+            new_rows, new_tok, new_sc = [], [], []
+            for b in range(B):
+                if done[b]:
+                    new_rows += [b * nb] * nb; new_tok += [c.pad_id] * nb; new_sc += [0.0] * nb
+                    continue
+                got = 0
+                for rank in range(2 * nb):
+                    beam, tok, sc = int(top_i[b, rank]) // c.vocab, int(top_i[b, rank]) % c.vocab, float(top_s[b, rank])
+                    if tok == c.eos_id:
+                        if rank >= nb:
+                            continue
+                        seq = ids_cpu[b * nb + beam].tolist()
+                        hyps[b].append((sc / (len(seq) ** length_penalty), seq))
+                    else:
+                        new_rows.append(b * nb + beam); new_tok.append(tok); new_sc.append(sc)
+                        got += 1
+                    if got == nb:
+                        break
+                if len(hyps[b]) >= nb:
+                    hyps[b] = sorted(hyps[b], key=lambda h: -h[0])[:nb]          # BeamHypotheses keeps the best num_beams
+                    if early_stopping:
+                        done[b] = True
+                    else:   # HF heuristic: stop when even the best open beam cannot beat the worst kept hypothesis
+                        done[b] = hyps[b][-1][0] >= float(top_s[b, 0]) / ((cur + 1) ** length_penalty)
+            rows = torch.tensor(new_rows, device=self.device)
+            ids = ids[rows].contiguous()
+            ids[:, cur] = torch.tensor(new_tok, device=self.device)
+            beam_scores = torch.tensor(new_sc, device=self.device).view(B, nb)
+            cur += 1
+            if all(done):
                 break
+        ids_cpu = ids[:, :cur].cpu()
+        out = torch.full((B, min(cur + 1, Lh)), c.pad_id, dtype=torch.int64)
+        for b in range(B):
+            if not done[b]:
+                for k in range(nb):
+                    seq = ids_cpu[b * nb + k].tolist()
+                    hyps[b].append((float(beam_scores[b, k]) / (len(seq) ** length_penalty), seq))
+            best = max(hyps[b], key=lambda h: h[0])[1]
+            best = best + [c.eos_id] if len(best) < out.shape[1] else best[:out.shape[1]]
+            out[b, :len(best)] = torch.tensor(best)
         self.training = was
-        return ids[:, :n]
+        return out.to(self.device)
 
     # ------------------------------------------------------------------ Lightning-shaped steps (:323-398)
     def training_step(self, batch, batch_idx):
