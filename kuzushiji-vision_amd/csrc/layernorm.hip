@@ -82,7 +82,7 @@ struct LnBwd {
     bf16_t* out16; unsigned o_thr16; float o_inv_keep; unsigned o_key;   // optional: bf16 copy of the TOTAL dx, dropout-masked
 };
 
-constexpr int BWD_ROWS = 32;  // rows per workgroup (4 waves x 8)
+constexpr int BWD_ROWS = 64;  // rows per workgroup (4 waves x 16): 32 rows -> +15 % time (gamma/beta atomics on 1.5k addresses contend), 128 -> too few workgroups
 
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) { dg[c] = make_float4(0, 0, 0, 0); db[c] = make_float4(0, 0, 0, 0); }
     const float invH = 1.f / (float)p.H;
+    float4 gmr[NC];                      // gamma: once per workgroup, not once per row
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gmr[c] = (lane + c * 64 < nc) ? ((const float4*)p.gamma)[lane + c * 64] : make_float4(0, 0, 0, 0);
+#pragma unroll 2
     for (int rr = 0; rr < BWD_ROWS / 4; ++rr) {
         const int row = blockIdx.x * BWD_ROWS + rr * 4 + w;
         if (row >= p.rows) break;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
                         d.z *= drop_keep(b1, 0, p.thr16, p.inv_keep); d.w *= drop_keep(b1, 1, p.thr16, p.inv_keep);
                     }
                 }
-                const float4 gm = ((const float4*)p.gamma)[i];
+                const float4 gm = gmr[c];
                 xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
                 gy[c] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
                 s1 += gy[c].x + gy[c].y + gy[c].z + gy[c].w;
