@@ -72,6 +72,13 @@ int kzv_model_sync_weights(kzv_model* m, void* stream);
 int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels,
                      float* d_loss, float* d_logits, int train, uint64_t seed, void* stream);
 
+/* Active decoder length.  Labels are [B, L] rows padded to L; when every sample's characters end before column
+ * t_active + 1, decoder positions >= t_active hold only padding: they are masked as attention keys, their targets are
+ * ignored by the loss and nothing reads their outputs, so the engine may run the decoder on the packed [B, t_active]
+ * prefix -- loss and gradients are unchanged (the reference computes and discards those positions).  Default after
+ * kzv_model_bind: L - 1 (everything).  kzv_forward_loss with d_logits != NULL requires the full length. */
+int kzv_set_active_length(kzv_model* m, int t_active);
+
 /* Decoder-only teacher-forced pass over `d_labels` [B,L] reusing the encoder states (and cross-attention K/V) of the
  * last kzv_forward_loss on this handle; writes the logits of position `pos` of every sample, fp32 [B,V].  Building
  * block of generation (TrOCRModel.forward inference branch, trocr_model.py:298-321): under the causal mask position

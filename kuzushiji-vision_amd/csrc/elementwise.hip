@@ -136,11 +136,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ gi
 // ------------------------------------------------------------------------------------- decoder embeddings
 // position ids: cumsum(ids != pad) * (ids != pad) + pad over the decoder INPUT ids labels[:, :-1];
 // count = number of targets labels[:, 1:] != pad.  One thread per batch row (T <= 127).
-__global__ void dec_prepare_kernel(const int64_t* __restrict__ labels, int B, int L, int pad, int max_pos,
+__global__ void dec_prepare_kernel(const int64_t* __restrict__ labels, int B, int L, int T, int pad, int max_pos,
                                    int* __restrict__ posids, float* count, int* err) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int T = L - 1;
     int run = 0, cnt = 0;
     for (int t = 0; t < T; ++t) {
         const bool np = labels[(int64_t)b * L + t] != pad;
@@ -327,8 +326,8 @@ int kzv_colsum_bf16(const bf16_t* g, int64_t ld, float* dbias, int M, int N, hip
     return kzv_check_launch("colsum_bf16");
 }
 
-int kzv_dec_prepare(const int64_t* labels, int B, int L, int pad, int max_pos, int* posids, float* count, int* err, hipStream_t s) {
-    hipLaunchKernelGGL(dec_prepare_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, labels, B, L, pad, max_pos, posids, count, err);
+int kzv_dec_prepare(const int64_t* labels, int B, int L, int T, int pad, int max_pos, int* posids, float* count, int* err, hipStream_t s) {
+    hipLaunchKernelGGL(dec_prepare_kernel, dim3(nblk(B, 64)), dim3(64), 0, s, labels, B, L, T, pad, max_pos, posids, count, err);
     return kzv_check_launch("dec_prepare");
 }
 

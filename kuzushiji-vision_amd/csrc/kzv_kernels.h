@@ -21,7 +21,7 @@ int kzv_embed_assemble_bwd(const float* dx0, bf16_t* dpatch, float* dcls, float*
 int kzv_cast_drop_colsum(const float* g, bf16_t* out, float* dbias, int M, int N, float drop_p, uint32_t key, hipStream_t s,
                          const bf16_t* gelu_pre = nullptr);
 int kzv_colsum_bf16(const bf16_t* g, int64_t ld, float* dbias, int M, int N, hipStream_t s);
-int kzv_dec_prepare(const int64_t* labels, int B, int L, int pad, int max_pos, int* posids, float* count, int* err, hipStream_t s);
+int kzv_dec_prepare(const int64_t* labels, int B, int L, int T, int pad, int max_pos, int* posids, float* count, int* err, hipStream_t s);
 int kzv_embed_gather(const int64_t* labels, int L, const int* posids, const float* word, const float* type0,
                      const float* postab, float* out, int B, int T, int Hd, hipStream_t s);
 int kzv_embed_scatter_bwd(const float* dsum, const int64_t* labels, int L, const int* posids, float* dword, float* dtype0,

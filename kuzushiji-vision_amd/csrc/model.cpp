@@ -50,7 +50,7 @@ struct kzv_model {
     std::vector<DecLayerP> dp;
     // bound state
     float* P = nullptr; float* G = nullptr; char* ws = nullptr; int64_t ws_bytes = 0;
-    int B = 0, L = 0, T = 0;
+    int B = 0, L = 0, T = 0, Ta = 0;
     bool bound = false, have_fwd = false, have_enc = false, train = false;
     uint64_t seed = 0;
     const int64_t* labels = nullptr;
@@ -305,7 +305,9 @@ int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, c
 int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss, float* d_logits, hipStream_t s,
             bool run_encoder = true, int logits_pos = -1) {
     const kzv_config& c = m->c;
-    const int B = m->B, T = m->T, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
+    // T = ACTIVE decoder length (kzv_set_active_length): positions >= T hold only padding in every sample, are
+    // masked as keys and carry no loss, so the decoder runs on the packed [B, T] prefix (rows b*T + t).
+    const int B = m->B, T = m->Ta, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
     const int Me = B * m->Se, Mp = B * m->np, Md = B * T;
     float* P = m->P;
     const float eps = c.ln_eps;
@@ -343,7 +345,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     m->have_enc = true;
     }   // run_encoder
     // ---- decoder embeddings (HF modeling_roberta.py:75-122,142-155) --------------------------------------
-    KZV_TRY(kzv_dec_prepare(labels, B, m->L, c.pad_id, c.max_pos, m->posids, m->count, m->err, s));
+    KZV_TRY(kzv_dec_prepare(labels, B, m->L, T, c.pad_id, c.max_pos, m->posids, m->count, m->err, s));
     KZV_TRY(kzv_embed_gather(labels, m->L, m->posids, P + m->word, P + m->dtype, P + m->dpos, m->emb_sum, B, T, Hd, s));
     KZV_TRY(kzv_ln_fwd_ex(m->emb_sum, P + m->eln_w, P + m->eln_b, m->xd0h, m->xd0, m->emb_st, Md, Hd, eps, 1, 0,
                           dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
@@ -378,7 +380,10 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     KZV_TRY(kzv_ce_fwd_bwd(m->logits, m->Vp, labels, m->L, B, T, m->V, c.pad_id, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, s));
     if (d_loss && hipMemcpyAsync(d_loss, m->loss_acc, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return kzv_fail(KZV_E_HIP, "forward: loss copy");
-    if (d_logits && logits_pos < 0) KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, Md, m->V, s));
+    if (d_logits && logits_pos < 0) {
+        if (T != m->T) return kzv_fail(KZV_E_STATE, "forward_loss: full logits need the full decoder length (kzv_set_active_length(m, L-1))");
+        KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, Md, m->V, s));
+    }
     if (d_logits && logits_pos >= 0)   // one position of every sample: rows b*T + pos
         KZV_TRY(kzv_copy_logits(m->logits + (int64_t)logits_pos * m->Vp, (int64_t)T * m->Vp, d_logits, B, m->V, s));
     return KZV_OK;
@@ -392,7 +397,7 @@ int lin_bwd_drop(const float* dx, bf16_t* dy, float* dbias, int M, int N, float 
 
 int backward_decoder(kzv_model* m, hipStream_t s) {
     const kzv_config& c = m->c;
-    const int B = m->B, T = m->T, Hd = m->Hd, Fd = m->Fd, He = m->He;
+    const int B = m->B, T = m->Ta, Hd = m->Hd, Fd = m->Fd, He = m->He;
     const int Mp = B * m->np, Md = B * T, Me = B * m->Se;
     float* P = m->P; float* G = m->G;
     const int CK = m->Ld * 2 * Hd;
@@ -576,7 +581,7 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
     const int64_t need = plan(m, (char*)d_workspace, batch, label_len);
     if (workspace_bytes < need) return kzv_fail(KZV_E_ARG, "model_bind: workspace %lld < required %lld", (long long)workspace_bytes, (long long)need);
     m->ws = (char*)d_workspace; m->ws_bytes = workspace_bytes;
-    m->B = batch; m->L = label_len; m->T = label_len - 1;
+    m->B = batch; m->L = label_len; m->T = label_len - 1; m->Ta = m->T;
     if (!kzv_zero_page()) return kzv_fail(KZV_E_HIP, "model_bind: zero page");
     // zero the bf16 weight region once (padding of transposed copies must read as 0), upload descriptors
     const int64_t wbytes = (char*)m->d_desc - (char*)d_workspace;
@@ -614,10 +619,18 @@ extern "C" int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const
     return rc;
 }
 
+extern "C" int kzv_set_active_length(kzv_model* m, int t_active) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "set_active_length: model not bound");
+    if (t_active < 1 || t_active > m->T) return kzv_fail(KZV_E_ARG, "set_active_length: must be in 1..%d", m->T);
+    if (m->have_fwd && t_active != m->Ta) m->have_fwd = false;   // saved activations belong to the old length
+    m->Ta = t_active;
+    return KZV_OK;
+}
+
 extern "C" int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos, float* d_logits, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_logits: model not bound");
     if (!m->have_enc) return kzv_fail(KZV_E_STATE, "decode_logits: call kzv_forward_loss on the images first");
-    if (!d_labels || !d_logits || pos < 0 || pos >= m->T) return kzv_fail(KZV_E_ARG, "decode_logits: bad argument");
+    if (!d_labels || !d_logits || pos < 0 || pos >= m->Ta) return kzv_fail(KZV_E_ARG, "decode_logits: position outside the active decoder length");
     m->train = false;
     m->have_fwd = false;     // decoder activations are overwritten: no backward after this
     return forward(m, nullptr, d_labels, nullptr, d_logits, (hipStream_t)stream, false, pos);

@@ -50,6 +50,7 @@ class TrOCRModel:
         self.logged: dict[str, list[float]] = {}
         self._optimizer = None
         self._step_seed = 0
+        self.trim_padding = True
 
         lib = L.load()
         c = self.cfg
@@ -204,6 +205,13 @@ class TrOCRModel:
             self._step_seed += 1
             seed = self._step_seed
         self._keep = (px, lab)   # inputs must outlive the asynchronous kernels (and backward reads labels)
+        # trailing all-padding decoder positions change neither loss nor gradients: run the decoder on the prefix that
+        # holds characters (one tiny device reduction + sync per step; full length when logits are returned)
+        t_act = Lh - 1
+        if not want_logits and self.trim_padding:
+            n_max = int((lab != self.cfg.pad_id).sum(dim=1).max().item())
+            t_act = max(1, min(Lh - 1, n_max))
+        L.check(L.load().kzv_set_active_length(self._h, t_act), "set_active_length")
         L.check(L.load().kzv_forward_loss(self._h, px.data_ptr(), lab.data_ptr(), self._loss.data_ptr(), L.ptr(logits),
                                           1 if self.training else 0, seed, L.stream_handle()), "kzv_forward_loss")
         return self._loss, logits
@@ -251,6 +259,7 @@ class TrOCRModel:
         self.forward_loss(px, ids, want_logits=False, seed=0)          # encoder + first decoder pass
 
         def logits_at(t):
+            L.check(lib.kzv_set_active_length(self._h, t + 1), "set_active_length")   # later positions are not needed
             L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
             return step_logits
 

@@ -368,3 +368,26 @@ def test_beam_search_generation(tmp_path):
     m2 = _make(cfg, tmp_path / "u", 6)
     g2 = m2.generate(pxt, max_length=12, num_beams=4).cpu().numpy()
     assert g2.shape[0] == 4 and (g2[:, 0] == cfg.bos_id).all() and g2.shape[1] <= 12
+
+
+def test_trailing_padding_trim_does_not_change_loss_or_gradients(tmp_path):
+    """kzv_set_active_length: running the decoder on the prefix that holds characters is exact -- positions that are
+    padding in every sample are masked keys with ignored targets (trocr_model.py:274-278,292)."""
+    cfg = _no_dropout(tiny_config())
+    m = _make(cfg, tmp_path, 13)
+    px, lab = synthetic_batch(cfg, 6, 36, seed=2, min_chars=2, max_chars=11)   # <= 11 characters in 36 columns
+    batch = (torch.from_numpy(px), torch.from_numpy(lab))
+    m.train()
+    res = {}
+    for trim in (False, True):
+        m.trim_padding = trim
+        loss, _ = m.forward_loss(*batch)
+        m.backward()
+        torch.cuda.synchronize()
+        res[trim] = (float(loss.item()), m.flat_grads.clone())
+    assert abs(res[True][0] - res[False][0]) < 1e-5
+    d = (res[True][1] - res[False][1]).abs().max().item()
+    assert d < 2e-4 * res[False][1].abs().max().item() + 1e-7, d     # float-atomic summation order only
+    # and against the oracle on the full length
+    r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 13)), px, lab)
+    assert abs(res[True][0] - r["loss"]) < 5e-3
