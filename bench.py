@@ -155,12 +155,15 @@ def main():
         T = args.label_len - 1
         ms, fl, n = collect(0)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        step_flops = train_flops_per_image(cfg, T) * args.batch
+        t_act = getattr(model, "last_active_length", T)     # decoder positions actually computed (trailing all-pad columns trimmed)
+        step_flops = train_flops_per_image(cfg, t_act) * args.batch
         others = {}
         for kind, name in ((1, "gemm_tn_kernel"), (2, "attn_fwd_kernel"), (3, "attn_bwd_kernel")):
             m2, f2, n2 = collect(kind)
             others[name] = {"ms_per_step": m2 / args.steps, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0,
                             "launches_per_step": n2 / args.steps}
+        DECPOS = (f"{t_act} of {T} computed: columns that are padding in every sample of the batch are skipped (exact: masked "
+                  "keys, ignored targets); labels hold U{8..60} characters (BASELINE.md section 4)")
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if os.path.exists(tj) and args.batch == 256 and args.dec_layers == 6:   # measured offline on this exact workload
@@ -175,6 +178,7 @@ def main():
                                    f"decoder {args.dec_layers}L/256/4h/768, V=4300 one-char vocab, labels [B,{args.label_len}], "
                                    f"dropout 0.1, clip 1.0, RAdamScheduleFree; BASELINE.json configs[{1 if world == 1 else 2}]",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "decoder_positions": DECPOS,
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> (bf16 MFMA 16x16x32, all nn.Linear fwd + dgrad)",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,

@@ -211,6 +211,7 @@ class TrOCRModel:
         if not want_logits and self.trim_padding:
             n_max = int((lab != self.cfg.pad_id).sum(dim=1).max().item())
             t_act = max(1, min(Lh - 1, n_max))
+        self.last_active_length = t_act
         L.check(L.load().kzv_set_active_length(self._h, t_act), "set_active_length")
         L.check(L.load().kzv_forward_loss(self._h, px.data_ptr(), lab.data_ptr(), self._loss.data_ptr(), L.ptr(logits),
                                           1 if self.training else 0, seed, L.stream_handle()), "kzv_forward_loss")
