@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
         char* d = smem + s * STAGE + w * 1024;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            if constexpr (ASM_DMA) glds16_asm(src[j], d + j * NW * 1024); else glds16(src[j], d + j * NW * 1024);
+            if constexpr (ASM_DMA) glds16_asm_m0(src[j], d + j * NW * 1024); else glds16(src[j], d + j * NW * 1024);
             src[j] += inc[j];
         }
     };
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
     // staging: piece j of wave w covers tile rows (w*4 + j)*4 .. +3 (4 rows x 256 B); lane -> row lane>>4,
     // slot lane&15; slot s of row r holds source chunk s ^ ((r & 7) << 1).
+    // Columns beyond N / K read the zero page with stride 0, so the steady-state issue is pointer + increment only.
     const char* pp[4]; const char* pq[4]; int64_t sp[4], sq[4]; int rowj[4];
     {
         const int r4 = lane >> 4;
@@ -270,26 +271,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
             const int chunk = (lane & 15) ^ ((row & 7) << 1);
             const int ncol = tnb * 128 + chunk * 8, kcol = tkb * 128 + chunk * 8;
             const bool vp = ncol < p.N, vq = kcol < p.K;
-            pp[j] = vp ? (const char*)(p.P + (int64_t)(t_begin + row) * p.ldp + ncol) : nullptr;
-            pq[j] = vq ? (const char*)(p.Q + (int64_t)(t_begin + row) * p.ldq + kcol) : nullptr;
-            sp[j] = 64 * p.ldp * 2; sq[j] = 64 * p.ldq * 2;
+            pp[j] = vp ? (const char*)(p.P + (int64_t)(t_begin + row) * p.ldp + ncol) : (const char*)p.zero16;
+            pq[j] = vq ? (const char*)(p.Q + (int64_t)(t_begin + row) * p.ldq + kcol) : (const char*)p.zero16;
+            sp[j] = vp ? 64 * p.ldp * 2 : 0; sq[j] = vq ? 64 * p.ldq * 2 : 0;
         }
     }
-    auto stage = [&](int s, int t0) {
+    auto stage = [&](int s) {                       // all 64 token rows of the stage are inside [t_begin, t_end)
         char* dP = smem + s * STAGE_BYTES + (w * 16) * 256;
         char* dQ = dP + 64 * 256;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool in = t0 + rowj[j] < t_end;
-            glds16_asm((in && pp[j]) ? pp[j] : (const char*)p.zero16, dP + j * 1024);
-            if (pp[j]) pp[j] += sp[j];
-        }
+        for (int j = 0; j < 4; ++j) { glds16_asm_m0(pp[j], dP + j * 1024); pp[j] += sp[j]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool in = t0 + rowj[j] < t_end;
-            glds16_asm((in && pq[j]) ? pq[j] : (const char*)p.zero16, dQ + j * 1024);
-            if (pq[j]) pq[j] += sq[j];
-        }
+        for (int j = 0; j < 4; ++j) { glds16_asm_m0(pq[j], dQ + j * 1024); pq[j] += sq[j]; }
+    };
+    auto stage_tail = [&](int s, int t0) {          // the ragged last stage of the token range: rows >= t_end read zeros
+        char* dP = smem + s * STAGE_BYTES + (w * 16) * 256;
+        char* dQ = dP + 64 * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_asm_m0(t0 + rowj[j] < t_end ? pp[j] : (const char*)p.zero16, dP + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_asm_m0(t0 + rowj[j] < t_end ? pq[j] : (const char*)p.zero16, dQ + j * 1024);
     };
 
     f32x4 acc[4][4];   // [k-tile i][n-tile j]: D rows = n (4g+r), D cols = k (l15)
@@ -349,13 +350,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     };
 
     const int nt = (t_end - t_begin + 63) / 64;
-    stage(0, t_begin);
+    const int nfull = (t_end - t_begin) / 64;       // stages 0 .. nfull-1 are complete; stage nfull (if any) is ragged
+    if (nfull > 0) stage(0); else stage_tail(0, t_begin);
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage t have landed
         __builtin_amdgcn_s_barrier();                        // ... and everybody's; buffer cur^1 is free again
         asm volatile("" ::: "memory");
-        if (t + 1 < nt) stage(cur ^ 1, t_begin + (t + 1) * 64);
+        if (t + 1 < nfull) stage(cur ^ 1);
+        else if (t + 1 < nt) stage_tail(cur ^ 1, t_begin + (t + 1) * 64);
         compute(cur, bias_wave && (t % tilesK) == tkb);
         cur ^= 1;
     }

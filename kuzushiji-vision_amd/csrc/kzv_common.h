@@ -99,6 +99,12 @@ __device__ __forceinline__ void glds16_asm(const void* g, void* lds_wave_base) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
+// Same, leaving M0 clobbered: only for kernels that issue EVERY LDS-DMA through this helper (no builtin LDS-DMA,
+// whose M0 the compiler tracks), e.g. gemm_tn.
+__device__ __forceinline__ void glds16_asm_m0(const void* g, void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(dst) : "memory");
+}
 __device__ __forceinline__ bf16x4 lds_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((KZV_LDS bf16x4*)p);
 }
