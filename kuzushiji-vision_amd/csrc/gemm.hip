@@ -17,6 +17,7 @@
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
+#include "gemm_nt.h"
 #include <cstdlib>
 
 namespace {
@@ -24,14 +25,6 @@ namespace {
 constexpr int BK = 64;
 constexpr int STAGE_BYTES = (128 + 128) * BK * 2;   // gemm_tn stage: 32 KiB
 constexpr int NT_LDS = 2 * STAGE_BYTES;             // gemm_tn: 64 KiB -> 2 workgroups / CU
-
-struct NtParams {
-    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const float* resid; bf16_t* aux;
-    const void* zero16;
-    int64_t lda, ldb, ldc, ldr, ldaux;
-    int M, N, K, n_valid;
-    unsigned drop_thr16; float drop_inv_keep; unsigned drop_key;
-};
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -197,35 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
             if (m >= p.M) continue;
             const f32x4 a4 = *(const f32x4*)(tile + rr * BN + ((c ^ (rr & 31)) << 2));
             float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
-            if (EPI == KZV_EPI_BF16) {
-                *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            } else if (EPI == KZV_EPI_F32) {
-                *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (EPI == KZV_EPI_GELU) {
-                *(uint2*)(p.aux + (int64_t)m * p.ldaux + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) =
-                    make_uint2(pack_bf2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf2(gelu_erf(v[2]), gelu_erf(v[3])));
-            } else if (EPI == KZV_EPI_GELU_F32) {
-                *(uint2*)(p.aux + (int64_t)m * p.ldaux + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) = make_float4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-            } else if (EPI == KZV_EPI_RESID) {
-                if (p.drop_thr16) {
-                    const unsigned e = (unsigned)m * (unsigned)p.N + (unsigned)n0;
-                    const unsigned b0 = drop_bits(p.drop_key, e >> 1), b1 = drop_bits(p.drop_key, (e >> 1) + 1);
-                    v[0] *= drop_keep(b0, 0, p.drop_thr16, p.drop_inv_keep);
-                    v[1] *= drop_keep(b0, 1, p.drop_thr16, p.drop_inv_keep);
-                    v[2] *= drop_keep(b1, 0, p.drop_thr16, p.drop_inv_keep);
-                    v[3] *= drop_keep(b1, 1, p.drop_thr16, p.drop_inv_keep);
-                }
-                *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) =
-                    make_float4(v[0] + r4[q].x, v[1] + r4[q].y, v[2] + r4[q].z, v[3] + r4[q].w);
-            } else if (EPI == KZV_EPI_DGELU) {
-                v[0] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].x & 0xffff)));
-                v[1] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].x >> 16)));
-                v[2] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].y & 0xffff)));
-                v[3] *= gelu_erf_grad(bf2f((bf16_t)(u2[q].y >> 16)));
-                *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            }
+            nt_emit<EPI>(p, m, n0, v, r4[q], u2[q]);
         }
     }
     }   // n0 < N
@@ -425,6 +390,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.drop_key = a->drop_key;
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
+    if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");   // large shapes: 256x256 eight-phase kernel
 #define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \
     case E: {                                                                                             \
         constexpr int lds = NS * (WM + WN) * 64 * KB * 2;                                                 \

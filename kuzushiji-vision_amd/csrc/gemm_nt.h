@@ -1,0 +1,50 @@
+// Shared between the two gemm_nt kernels (gemm.hip: 128x128 two-stage; gemm_nt256.hip: 256x256 eight-phase):
+// launch parameters and the fused per-row epilogue.
+#pragma once
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+
+struct NtParams {
+    const bf16_t* A; const bf16_t* B; void* C; const float* bias; const float* resid; bf16_t* aux;
+    const void* zero16;
+    int64_t lda, ldb, ldc, ldr, ldaux;
+    int M, N, K, n_valid;
+    unsigned drop_thr16; float drop_inv_keep; unsigned drop_key;
+};
+
+// One thread finishes 4 consecutive columns n0..n0+3 of output row m: v = accumulator + bias on entry;
+// r4 = the residual (RESID), u2 = the saved pre-activation as 4 bf16 (DGELU), both loaded by the caller.
+template <int EPI>
+__device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float (&v)[4], const float4& r4, const uint2& u2) {
+    if (EPI == KZV_EPI_BF16) {
+        *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    } else if (EPI == KZV_EPI_F32) {
+        *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (EPI == KZV_EPI_GELU) {
+        *(uint2*)(p.aux + (int64_t)m * p.ldaux + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) =
+            make_uint2(pack_bf2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf2(gelu_erf(v[2]), gelu_erf(v[3])));
+    } else if (EPI == KZV_EPI_GELU_F32) {
+        *(uint2*)(p.aux + (int64_t)m * p.ldaux + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) = make_float4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+    } else if (EPI == KZV_EPI_RESID) {
+        if (p.drop_thr16) {
+            const unsigned e = (unsigned)m * (unsigned)p.N + (unsigned)n0;
+            const unsigned b0 = drop_bits(p.drop_key, e >> 1), b1 = drop_bits(p.drop_key, (e >> 1) + 1);
+            v[0] *= drop_keep(b0, 0, p.drop_thr16, p.drop_inv_keep);
+            v[1] *= drop_keep(b0, 1, p.drop_thr16, p.drop_inv_keep);
+            v[2] *= drop_keep(b1, 0, p.drop_thr16, p.drop_inv_keep);
+            v[3] *= drop_keep(b1, 1, p.drop_thr16, p.drop_inv_keep);
+        }
+        *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) = make_float4(v[0] + r4.x, v[1] + r4.y, v[2] + r4.z, v[3] + r4.w);
+    } else if (EPI == KZV_EPI_DGELU) {
+        v[0] *= gelu_erf_grad(bf2f((bf16_t)(u2.x & 0xffff)));
+        v[1] *= gelu_erf_grad(bf2f((bf16_t)(u2.x >> 16)));
+        v[2] *= gelu_erf_grad(bf2f((bf16_t)(u2.y & 0xffff)));
+        v[3] *= gelu_erf_grad(bf2f((bf16_t)(u2.y >> 16)));
+        *(uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    }
+}
+
+// gemm_nt256.hip: returns 1 when it took the launch, 0 when the shape is left to the 128x128 kernel.
+int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);

@@ -62,6 +62,34 @@ def test_gemm_nt_epilogues(lib, M, N, K):
     assert (got.double() - want).abs().max().item() < 2 ** -7 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,nv", [(24600, 1024, 128, 1024), (24600, 1024, 320, 1000), (41216, 768, 768, 768)])
+def test_gemm_nt_large_shapes_take_the_256x256_kernel(lib, M, N, K, nv):
+    """>= 384 tiles of 256x256 -> gemm_nt256.hip (eight-phase schedule): ragged M, odd and minimal K-tile counts,
+    n_valid < N (clamped B rows, zeroed columns), all epilogue families."""
+    torch.manual_seed(K)
+    A = torch.randn(M, K, device=DEV).bfloat16()
+    B = (torch.randn(nv, K, device=DEV) * 0.1).bfloat16()
+    bias = torch.randn(nv, device=DEV)
+    ref = A.float() @ B.float().t() + bias
+    scale = ref.abs().max().item()
+    got = _gemm_nt(lib, A, B, L.EPI_F32, bias, n_store=N)
+    assert (got[:, :nv] - ref).abs().max().item() < 2e-5 * scale + 1e-5
+    assert torch.all(got[:, nv:] == 0)
+    got = _gemm_nt(lib, A, B, L.EPI_BF16, bias, n_store=N).float()
+    assert (got[:, :nv] - ref).abs().max().item() < 2 ** -8 * scale
+    res = torch.randn(M, N, device=DEV)
+    got = _gemm_nt(lib, A, B, L.EPI_RESID, bias, n_store=N, resid=res)
+    assert (got[:, :nv] - ref - res[:, :nv]).abs().max().item() < 2e-5 * scale + 1e-5
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    got = _gemm_nt(lib, A, B, L.EPI_GELU, bias, n_store=N, aux=aux).float()
+    assert (got[:, :nv] - torch.nn.functional.gelu(ref)).abs().max().item() < 2 ** -8 * scale
+    assert (aux[:, :nv].float() - ref).abs().max().item() < 2 ** -8 * scale
+    # run-to-run determinism (a staging race would show up as rare differing tiles)
+    first = _gemm_nt(lib, A, B, L.EPI_F32, bias, n_store=N)
+    for _ in range(5):
+        assert torch.equal(_gemm_nt(lib, A, B, L.EPI_F32, bias, n_store=N), first)
+
+
 def test_gemm_nt_padded_columns_are_zero(lib):
     A = torch.randn(130, 64, device=DEV).bfloat16()
     B = torch.randn(157, 64, device=DEV).bfloat16()
