@@ -149,6 +149,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
     constexpr int CPR = BN / 4, RSTEP = NW * 64 / CPR;
     const int c = tid % CPR;
     const int n0 = tn * BN + c * 4;
+    const bool interior = tm * BM + BM <= p.M && tn * BN + BN <= p.N;      // wave-uniform
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (EPI != KZV_EPI_DGELU && p.bias && n0 < p.N) {
 #pragma unroll
@@ -169,31 +170,45 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
         }
     }
     __syncthreads();
-    if (n0 < p.N) {
     // rows are processed 8 at a time with the residual / aux loads of the batch issued up front, so the
-    // per-row global-load latency overlaps instead of serialising 16 dependent round trips per tile
+    // per-row global-load latency overlaps instead of serialising 16 dependent round trips per tile.
+    // Interior tiles are branch-free: per-row guards make hipcc's waitcnt pass lose count at every join and put
+    // `s_waitcnt vmcnt(0)` in front of each store (every store then waits for the previous one to complete).
     constexpr int NP = RC / RSTEP;
     static_assert(NP % 8 == 0, "row passes come in batches of 8");
+    if (interior) {
 #pragma unroll
     for (int pb = 0; pb < NP; pb += 8) {
         float4 r4[8]; uint2 u2[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int m = tm * BM + r0 + tid / CPR + (pb + q) * RSTEP;
-            if (EPI == KZV_EPI_RESID) r4[q] = m < p.M ? *(const float4*)(p.resid + (int64_t)m * p.ldr + n0) : make_float4(0, 0, 0, 0);
-            if (EPI == KZV_EPI_DGELU) u2[q] = m < p.M ? *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0) : make_uint2(0, 0);
+            if (EPI == KZV_EPI_RESID) r4[q] = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
+            if (EPI == KZV_EPI_DGELU) u2[q] = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int rr = tid / CPR + (pb + q) * RSTEP;
             const int m = tm * BM + r0 + rr;
-            if (m >= p.M) continue;
             const f32x4 a4 = *(const f32x4*)(tile + rr * BN + ((c ^ (rr & 31)) << 2));
             float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
             nt_emit<EPI>(p, m, n0, v, r4[q], u2[q]);
         }
     }
-    }   // n0 < N
+    } else if (n0 < p.N) {
+#pragma unroll 1
+    for (int q = 0; q < NP; ++q) {
+        const int rr = tid / CPR + q * RSTEP;
+        const int m = tm * BM + r0 + rr;
+        if (m >= p.M) continue;
+        float4 r4 = make_float4(0, 0, 0, 0); uint2 u2 = make_uint2(0, 0);
+        if (EPI == KZV_EPI_RESID) r4 = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
+        if (EPI == KZV_EPI_DGELU) u2 = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
+        const f32x4 a4 = *(const f32x4*)(tile + rr * BN + ((c ^ (rr & 31)) << 2));
+        float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
+        nt_emit<EPI>(p, m, n0, v, r4, u2);
+    }
+    }
   }     // row chunks
 }
 
@@ -390,6 +405,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.drop_key = a->drop_key;
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
+    if (getenv("KZV_NT256P") && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");  // large shapes: persistent 256x256 eight-phase kernel
     if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");   // large shapes: 256x256 eight-phase kernel
 #define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \
     case E: {                                                                                             \

@@ -48,3 +48,5 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
 
 // gemm_nt256.hip: returns 1 when it took the launch, 0 when the shape is left to the 128x128 kernel.
 int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);
+// gemm_nt256p.hip (persistent variant of the same schedule): same contract.
+int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s);

@@ -51,13 +51,17 @@ template <int N> __device__ __forceinline__ void vmcnt() {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p) {
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wr = w >> 2, wc = w & 3;
     const int tilesN = (p.N + 255) / 256, tilesM = (p.M + 255) / 256;
+    if (stagger > 0 && blockIdx.x < 256) {          // EXPERIMENT: de-phase the CUs' epilogue bursts
+        const int n = ((blockIdx.x >> 3) % 3) * stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int id = xcd_remap(blockIdx.x, tilesM * tilesN);
     const int tm = id / tilesN, tn = id - tm * tilesN;
 
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p) {
     float* tile = (float*)smem;                    // [128][256] fp32, 16-B chunks XOR-swizzled by (row & 31)
     const int c4 = tid & 63;
     const int n0 = tn * 256 + c4 * 4;
+    const bool interior = tm * 256 + 256 <= p.M && tn * 256 + 256 <= p.n_valid;    // wave-uniform (n_valid <= N)
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     bool nv[4];
 #pragma unroll
@@ -195,7 +200,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p) {
             }
         }
         __syncthreads();
-        if (n0 < p.N) {
+        // Interior tiles (all of them when M, N are multiples of 256) take a branch-free path: with per-row guards
+        // hipcc's waitcnt pass loses count at every join and puts `s_waitcnt vmcnt(0)` in front of each store, i.e.
+        // every store waits for the previous one to complete.
+        if (interior) {
 #pragma unroll
             for (int pb = 0; pb < 16; pb += 8) {
                 float4 r4[8]; uint2 u2[8];
@@ -203,20 +211,32 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p) {
                 for (int q = 0; q < 8; ++q) {
                     const int lr = (pb + q) * 8 + w;
                     const int m = tm * 256 + (lr >> 6) * 128 + c * 64 + (lr & 63);
-                    if (EPI == KZV_EPI_RESID) r4[q] = m < p.M ? *(const float4*)(p.resid + (int64_t)m * p.ldr + n0) : make_float4(0, 0, 0, 0);
-                    if (EPI == KZV_EPI_DGELU) u2[q] = m < p.M ? *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0) : make_uint2(0, 0);
+                    if (EPI == KZV_EPI_RESID) r4[q] = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
+                    if (EPI == KZV_EPI_DGELU) u2[q] = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int lr = (pb + q) * 8 + w;
                     const int m = tm * 256 + (lr >> 6) * 128 + c * 64 + (lr & 63);
-                    if (m >= p.M) continue;
                     const f32x4 a4 = *(const f32x4*)(tile + lr * 256 + ((c4 ^ (lr & 31)) << 2));
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = nv[r] ? a4[r] + b4[r] : 0.f;
+                    float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
                     nt_emit<EPI>(p, m, n0, v, r4[q], u2[q]);
                 }
+            }
+        } else if (n0 < p.N) {
+#pragma unroll 1
+            for (int q = 0; q < 16; ++q) {
+                const int lr = q * 8 + w;
+                const int m = tm * 256 + (lr >> 6) * 128 + c * 64 + (lr & 63);
+                if (m >= p.M) continue;
+                float4 r4 = make_float4(0, 0, 0, 0); uint2 u2 = make_uint2(0, 0);
+                if (EPI == KZV_EPI_RESID) r4 = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
+                if (EPI == KZV_EPI_DGELU) u2 = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
+                const f32x4 a4 = *(const f32x4*)(tile + lr * 256 + ((c4 ^ (lr & 31)) << 2));
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = nv[r] ? a4[r] + b4[r] : 0.f;
+                nt_emit<EPI>(p, m, n0, v, r4, u2);
             }
         }
     }
@@ -235,11 +255,13 @@ int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s) {
     // below ~1.5 rounds of the 256 CUs the 128x128 kernel (4x the tiles, 2 workgroups per CU) fills the chip better
     if (p.K < 128 || tiles < nt256_min_tiles()) return 0;
     if ((uint64_t)256 * (uint64_t)p.lda * 2 > 0xffffffffull || (uint64_t)p.n_valid * (uint64_t)p.ldb * 2 > 0xffffffffull) return 0;   // 32-bit DMA offsets
+    static int stag = -1;
+    if (stag < 0) { const char* e = getenv("KZV_NT256_STAGGER"); stag = e ? atoi(e) : 0; }
 #define KZV_NT256_CASE(E)                                                                                           \
     case E: {                                                                                                       \
         static bool attr_done = false;                                                                              \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
-        hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3(tiles), dim3(512), LDS_BYTES, s, p);                        \
+        hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3(tiles), dim3(512), LDS_BYTES, s, p, stag);                        \
     } break;
     switch (epilogue) {
         KZV_NT256_CASE(KZV_EPI_BF16) KZV_NT256_CASE(KZV_EPI_F32) KZV_NT256_CASE(KZV_EPI_GELU)

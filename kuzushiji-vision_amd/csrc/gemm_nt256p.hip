@@ -1,0 +1,308 @@
+// gemm_nt, persistent 256x256 eight-phase kernel for gfx950 (MI355X).
+//
+// Same tile, LDS ring, phase schedule and ping-pong as gemm_nt256.hip (read its header first); what changes:
+//
+//  * ONE workgroup per CU walks a sequence of output tiles (tile = seq * gridDim + virtual block), and the K-tiles of
+//    consecutive output tiles form ONE stream through the LDS ring: while the last K-tiles of tile i are multiplied,
+//    the half-tiles of tile i+1 are already in flight, so no tile pays a cold prologue (memory latency with the MFMA
+//    pipe idle) after the first.
+//  * The epilogue never touches the ring: each wave drains its own accumulators through a wave-private 4-KiB LDS
+//    patch (bytes 128K..160K of the CU's LDS) -- fp32 half-quadrants of 32 rows x 32 columns are written in MFMA
+//    layout, read back row-major (8 rows x 128 B per wave-instruction) and stored / combined with the residual or
+//    the saved pre-activation.  No workgroup barrier is involved, so the two wave groups drain half a phase apart
+//    and the next tile's loads keep landing meanwhile.
+//
+// vmcnt bookkeeping across a drain.  vmcnt counts this wave's VMEM operations in issue order (loads and stores
+// retire in order on gfx9-family parts).  A wait that must retire an LDS-DMA load issued BEFORE the drain may leave
+// outstanding every operation issued after that load: the usual 8 (four half-tiles) plus the D loads/stores of the
+// drain.  D is only credited for interior tiles, where every row and column is stored (an edge tile skips some
+// stores; crediting too few is merely conservative, crediting too many would be a race).
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "gemm_nt.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int HT_BYTES = 128 * 128;        // half-tile: 128 rows x 64 bf16
+constexpr int BUF_BYTES = 4 * HT_BYTES;    // A-h0, A-h1, B-h0, B-h1
+constexpr int RING_BYTES = 2 * BUF_BYTES;  // 128 KiB
+constexpr int LDS_BYTES = RING_BYTES + 8 * 4096;   // + one 4-KiB drain patch per wave = 160 KiB
+constexpr int KA0 = 0, KA1 = 1, KB0 = 2, KB1 = 3;
+
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else if constexpr (N == 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else static_assert(N == 0, "add the vmcnt literal");
+}
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+
+// VMEM operations one wave issues while draining an interior tile (32 four-column groups per lane)
+template <int EPI> constexpr int drain_ops() {
+    return (EPI == KZV_EPI_BF16 || EPI == KZV_EPI_F32) ? 32 : 64;   // GELU*: two stores; RESID/DGELU: load + store
+}
+
+struct TileSrc {            // where the next half-tiles of one half index (h) come from
+    const char* a; const char* b;      // wave-uniform bases (A: tile row panel; B: absolute)
+    unsigned va[2], vb[2];             // per-lane byte offsets of this wave's two 1-KiB pieces
+    int kt, seq; bool valid;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wr = w >> 2, wc = w & 3;
+    const int G = gridDim.x;
+    // blocks land on XCD (blockIdx % 8): give each XCD a contiguous run of every step's tiles (shared A row panels)
+    const int vblk = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nk = p.K / 64;                       // even, >= 2 (checked by the launcher)
+
+    auto set_tile = [&](TileSrc& s, int seq, int h) {
+        s.seq = seq; s.kt = 0;
+        const int id = seq * G + vblk;
+        s.valid = id < tiles;
+        const int idc = s.valid ? id : 0;
+        const int tm = __builtin_amdgcn_readfirstlane(idc / tilesN);
+        const int tn = idc - tm * tilesN;
+        s.a = (const char*)(p.A + (int64_t)tm * 256 * p.lda);
+        s.b = (const char*)p.B;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));       // recompute the lane terms here: hoisted, they would live (and spill) across the K loop
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 64 + w * 8 + (ln >> 3);
+            const unsigned cb = (unsigned)(((ln & 7) ^ (r & 7)) * 16);
+            int arow = (r >> 6) * 128 + h * 64 + (r & 63);
+            arow = min(tm * 256 + arow, p.M - 1) - tm * 256;            // rows beyond M: clamp (never stored)
+            s.va[j] = (unsigned)arow * (unsigned)(p.lda * 2) + cb;
+            int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
+            bcol = min(tn * 256 + bcol, p.n_valid - 1);                 // columns beyond n_valid: clamp (stored as 0)
+            s.vb[j] = (unsigned)bcol * (unsigned)(p.ldb * 2) + cb;
+        }
+    };
+    auto advance = [&](TileSrc& s, int h) {
+        if (++s.kt == nk) set_tile(s, s.seq + 1, h);
+    };
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)smem) + (unsigned)w * 1024u);
+    auto stageA = [&](const TileSrc& s, int buf, int h) {
+        const char* sb = s.a + (int64_t)s.kt * 128;
+        const unsigned d = ldsw + (unsigned)(buf * BUF_BYTES + (KA0 + h) * HT_BYTES);
+        glds16_s(s.va[0], sb, d); glds16_s(s.va[1], sb, d + 8192u);
+    };
+    auto stageB = [&](const TileSrc& s, int buf, int h) {
+        const char* sb = s.b + (int64_t)s.kt * 128;
+        const unsigned d = ldsw + (unsigned)(buf * BUF_BYTES + (KB0 + h) * HT_BYTES);
+        glds16_s(s.vb[0], sb, d); glds16_s(s.vb[1], sb, d + 8192u);
+    };
+
+    f32x4 acc[8][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    const int sw = l15 & 7;
+    const int slot0 = (g ^ sw) << 4, slot1 = ((4 + g) ^ sw) << 4;
+    const int a_off = (wr * 64 + l15) * 128, b_off = (wc * 32 + l15) * 128;
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto readA = [&](int buf, int mh) {
+        const char* b = smem + buf * BUF_BYTES + (KA0 + mh) * HT_BYTES + a_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *(const bf16x8*)(b + i * 2048 + slot0);
+            fa[i][1] = *(const bf16x8*)(b + i * 2048 + slot1);
+        }
+    };
+    auto readB = [&](int buf, int nh, bf16x8 (&fb)[2][2]) {
+        const char* b = smem + buf * BUF_BYTES + (KB0 + nh) * HT_BYTES + b_off;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = *(const bf16x8*)(b + j * 2048 + slot0);
+            fb[j][1] = *(const bf16x8*)(b + j * 2048 + slot1);
+        }
+    };
+    auto mma = [&](int mh, int nh, const bf16x8 (&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kh], fa[i][kh], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    TileSrc s1, s2;                    // s1 feeds A-h1/B-h1 of stream K-tile u+1, s2 feeds A-h0/B-h0 of K-tile u+2
+    constexpr int D = drain_ops<EPI>();
+    constexpr int W8 = cmin(63, 8 + D), W4 = cmin(63, 4 + D);
+
+    // One K-tile of the stream = four phases (gemm_nt256.hip).  e1 / e2: stream K-tiles u+1 / u+2 exist.
+    // `after_drain`: this is the first K-tile after a credited drain (waits widened by D).
+    auto ktile = [&](auto bufc, bool after_drain) {
+        constexpr int BUF = decltype(bufc)::value;
+        const bool e1 = s1.valid, e2 = s2.valid;
+        // p1
+        readA(BUF, 0); readB(BUF, 0, fb0);
+        if (e1) { stageB(s1, BUF ^ 1, 1); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); } else vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        mma(0, 0, fb0);
+        __builtin_amdgcn_s_barrier();
+        // p2
+        readB(BUF, 1, fb1);
+        if (e1) { stageA(s1, BUF ^ 1, 1); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); } else vmcnt<0>();
+        advance(s1, 1);
+        __builtin_amdgcn_s_barrier();
+        mma(0, 1, fb1);
+        __builtin_amdgcn_s_barrier();
+        // p3
+        readA(BUF, 1);
+        if (e2) stageA(s2, BUF, 0);
+        __builtin_amdgcn_s_barrier();
+        mma(1, 1, fb1);
+        __builtin_amdgcn_s_barrier();
+        // p4
+        if (e2) { stageB(s2, BUF, 0); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); }
+        else if (e1) { if (after_drain) vmcnt<W4>(); else vmcnt<4>(); }
+        advance(s2, 0);
+        __builtin_amdgcn_s_barrier();
+        mma(1, 0, fb0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+    // ---- drain: this wave's 128x64 accumulators -> global, through its private LDS patch ----
+    auto drain = [&](int tm, int tn) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));       // as in set_tile: keep the drain's address terms out of the K loop's live set
+        float* patch = (float*)(smem + RING_BYTES + w * 4096);        // [32 rows][32 cols] fp32, chunks XOR (row & 7)
+        const int prow = ln >> 3, pchunk = ln & 7;
+        const int l15 = ln & 15, g = ln >> 4;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            const int n0 = tn * 256 + wc * 64 + nh * 32 + pchunk * 4;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            bool nv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nv[r] = n0 + r < p.n_valid;
+                if (EPI != KZV_EPI_DGELU && p.bias && nv[r]) b4[r] = p.bias[n0 + r];
+            }
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int m0 = tm * 256 + wr * 128 + mh * 64 + half * 32;
+                    float4 r4[4]; uint2 u2[4];
+                    if (n0 < p.N) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int m = m0 + q * 8 + prow;
+                            if (EPI == KZV_EPI_RESID) r4[q] = m < p.M ? *(const float4*)(p.resid + (int64_t)m * p.ldr + n0) : make_float4(0, 0, 0, 0);
+                            if (EPI == KZV_EPI_DGELU) u2[q] = m < p.M ? *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0) : make_uint2(0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int row = i2 * 16 + l15, chunk = j * 4 + g;
+                            *(f32x4*)(patch + row * 32 + ((chunk ^ (row & 7)) << 2)) = acc[mh * 4 + half * 2 + i2][nh * 2 + j];
+                        }
+                    if (n0 < p.N) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int row = q * 8 + prow;
+                            const int m = m0 + row;
+                            const f32x4 a4 = *(const f32x4*)(patch + row * 32 + ((pchunk ^ (row & 7)) << 2));
+                            if (m >= p.M) continue;
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = nv[r] ? a4[r] + b4[r] : 0.f;
+                            nt_emit<EPI>(p, m, n0, v, r4[q], u2[q]);
+                        }
+                    }
+                }
+        }
+    };
+
+    // ---- the stream ----
+    set_tile(s2, 0, 0); set_tile(s1, 0, 1);
+    stageA(s2, 0, 0); stageB(s2, 0, 0); stageB(s1, 0, 1); stageA(s1, 0, 1);
+    advance(s2, 0);                                 // nk >= 2: still tile 0, K-tile 1
+    stageA(s2, 1, 0); stageB(s2, 1, 0);
+    advance(s2, 0); advance(s1, 1);
+    vmcnt<8>();                                     // A-h0(0), B-h0(0) landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // waves 4..7 run one barrier interval behind
+    bool credit = false;                            // previous drain was of an interior tile
+    for (int seq = 0; ; ++seq) {
+        const int id = seq * G + vblk;
+        if (id >= tiles) break;
+        const int tm = __builtin_amdgcn_readfirstlane(id / tilesN);
+        const int tn = id - tm * tilesN;
+        // nk is even (launcher): every tile starts on ring buffer 0, so the two K-tile bodies alternate statically
+        // (selecting the body by a run-time parity made hipcc spill half the accumulators)
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(I0{}, credit && kt == 0);
+            ktile(I1{}, false);
+        }
+        drain(tm, tn);
+        credit = tm * 256 + 256 <= p.M && tn * 256 + 256 <= p.N;
+        zero_acc();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
+}
+
+int nt256p_min_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("KZV_NT256P_MIN_TILES"); v = e ? atoi(e) : 384; }
+    return v;
+}
+int device_cus() {
+    static int v = -1;
+    if (v < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        v = n;
+    }
+    return v;
+}
+
+}  // namespace
+
+int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s) {
+    const int tilesN = (p.N + 255) / 256;
+    const int tiles = ((p.M + 255) / 256) * tilesN;
+    if (p.K < 128 || p.K % 128 || tiles < nt256p_min_tiles()) return 0;   // even number of K-tiles (odd: gemm_nt256.hip)
+    if ((uint64_t)256 * (uint64_t)p.lda * 2 > 0xffffffffull || (uint64_t)p.n_valid * (uint64_t)p.ldb * 2 > 0xffffffffull) return 0;   // 32-bit DMA offsets
+    const int grid = tiles < device_cus() ? tiles : device_cus();
+#define KZV_NT256P_CASE(E)                                                                                          \
+    case E: {                                                                                                       \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<E>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN);         \
+    } break;
+    switch (epilogue) {
+        KZV_NT256P_CASE(KZV_EPI_BF16) KZV_NT256P_CASE(KZV_EPI_F32) KZV_NT256P_CASE(KZV_EPI_GELU)
+        KZV_NT256P_CASE(KZV_EPI_RESID) KZV_NT256P_CASE(KZV_EPI_DGELU) KZV_NT256P_CASE(KZV_EPI_GELU_F32)
+        default: return 0;
+    }
+#undef KZV_NT256P_CASE
+    return 1;
+}
