@@ -405,8 +405,14 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.drop_key = a->drop_key;
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
-    if (getenv("KZV_NT256P") && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");  // large shapes: persistent 256x256 eight-phase kernel
-    if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");   // large shapes: 256x256 eight-phase kernel
+    // large shapes: 256x256 eight-phase kernels.  The persistent one wins wherever its per-wave drain is light (one
+    // store per element: -2..-10 % vs the one-tile-per-workgroup kernel); the two-store GELU epilogues are faster through
+    // the workgroup-wide LDS epilogue of gemm_nt256.hip (512-B / 1-KiB row segments).
+    static int use_p = -1;
+    if (use_p < 0) { const char* e = getenv("KZV_NT256P"); use_p = e ? atoi(e) : 1; }
+    const bool two_store = epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32;
+    if (use_p && !two_store && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
+    if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
 #define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \
     case E: {                                                                                             \
         constexpr int lds = NS * (WM + WN) * 64 * KB * 2;                                                 \

@@ -51,17 +51,13 @@ template <int N> __device__ __forceinline__ void vmcnt() {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p, const int stagger) {
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wr = w >> 2, wc = w & 3;
     const int tilesN = (p.N + 255) / 256, tilesM = (p.M + 255) / 256;
-    if (stagger > 0 && blockIdx.x < 256) {          // EXPERIMENT: de-phase the CUs' epilogue bursts
-        const int n = ((blockIdx.x >> 3) % 3) * stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int id = xcd_remap(blockIdx.x, tilesM * tilesN);
     const int tm = id / tilesN, tn = id - tm * tilesN;
 
@@ -255,13 +251,11 @@ int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s) {
     // below ~1.5 rounds of the 256 CUs the 128x128 kernel (4x the tiles, 2 workgroups per CU) fills the chip better
     if (p.K < 128 || tiles < nt256_min_tiles()) return 0;
     if ((uint64_t)256 * (uint64_t)p.lda * 2 > 0xffffffffull || (uint64_t)p.n_valid * (uint64_t)p.ldb * 2 > 0xffffffffull) return 0;   // 32-bit DMA offsets
-    static int stag = -1;
-    if (stag < 0) { const char* e = getenv("KZV_NT256_STAGGER"); stag = e ? atoi(e) : 0; }
 #define KZV_NT256_CASE(E)                                                                                           \
     case E: {                                                                                                       \
         static bool attr_done = false;                                                                              \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
-        hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3(tiles), dim3(512), LDS_BYTES, s, p, stag);                        \
+        hipLaunchKernelGGL((gemm_nt256_kernel<E>), dim3(tiles), dim3(512), LDS_BYTES, s, p);                        \
     } break;
     switch (epilogue) {
         KZV_NT256_CASE(KZV_EPI_BF16) KZV_NT256_CASE(KZV_EPI_F32) KZV_NT256_CASE(KZV_EPI_GELU)

@@ -7,9 +7,9 @@
 //    the half-tiles of tile i+1 are already in flight, so no tile pays a cold prologue (memory latency with the MFMA
 //    pipe idle) after the first.
 //  * The epilogue never touches the ring: each wave drains its own accumulators through a wave-private 4-KiB LDS
-//    patch (bytes 128K..160K of the CU's LDS) -- fp32 half-quadrants of 32 rows x 32 columns are written in MFMA
-//    layout, read back row-major (8 rows x 128 B per wave-instruction) and stored / combined with the residual or
-//    the saved pre-activation.  No workgroup barrier is involved, so the two wave groups drain half a phase apart
+//    patch (bytes 128K..160K of the CU's LDS) -- one accumulator row block (16 rows x the wave's 64 columns, fp32)
+//    at a time is written in MFMA layout, read back row-major (4 rows x 256 B per wave-instruction) and stored /
+//    combined with the residual or the saved pre-activation.  No workgroup barrier is involved, so the two wave groups drain half a phase apart
 //    and the next tile's loads keep landing meanwhile.
 //
 // vmcnt bookkeeping across a drain.  vmcnt counts this wave's VMEM operations in issue order (loads and stores
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
 
     // One K-tile of the stream = four phases (gemm_nt256.hip).  e1 / e2: stream K-tiles u+1 / u+2 exist.
     // `after_drain`: this is the first K-tile after a credited drain (waits widened by D).
-    auto ktile = [&](auto bufc, bool after_drain) {
+    auto ktile = [&](auto bufc, bool after_drain, bool defer) {
         constexpr int BUF = decltype(bufc)::value;
-        const bool e1 = s1.valid, e2 = s2.valid;
+        const bool e1 = s1.valid, e2 = s2.valid && !defer;
         // p1
         readA(BUF, 0); readB(BUF, 0, fb0);
         if (e1) { stageB(s1, BUF ^ 1, 1); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); } else vmcnt<2>();
@@ -177,9 +177,8 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
         mma(1, 1, fb1);
         __builtin_amdgcn_s_barrier();
         // p4
-        if (e2) { stageB(s2, BUF, 0); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); }
-        else if (e1) { if (after_drain) vmcnt<W4>(); else vmcnt<4>(); }
-        advance(s2, 0);
+        if (e2) { stageB(s2, BUF, 0); vmcnt<8>(); advance(s2, 0); }
+        else if (e1) vmcnt<4>();                      // tail, or refills deferred past the drain: only p1/p2's are newer
         __builtin_amdgcn_s_barrier();
         mma(1, 0, fb0);
         __builtin_amdgcn_s_barrier();
@@ -187,57 +186,78 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
     // ---- drain: this wave's 128x64 accumulators -> global, through its private LDS patch ----
-    auto drain = [&](int tm, int tn) {
+    auto drain = [&](int tm, int tn, auto interiorc) {
+        constexpr bool interior = decltype(interiorc)::value;
         int ln = lane;
         asm volatile("" : "+v"(ln));       // as in set_tile: keep the drain's address terms out of the K loop's live set
-        float* patch = (float*)(smem + RING_BYTES + w * 4096);        // [32 rows][32 cols] fp32, chunks XOR (row & 7)
-        const int prow = ln >> 3, pchunk = ln & 7;
+        // patch = one accumulator row block: [16 rows][64 cols] fp32 (256-B rows), 16-B chunks XOR (row & 15)
+        float* patch = (float*)(smem + RING_BYTES + w * 4096);
+        const int prow = ln >> 4, pchunk = ln & 15;           // read-back: 4 rows x 256 B per wave-instruction
         const int l15 = ln & 15, g = ln >> 4;
+        // wave columns: accumulator column block j (nh = j >> 1) sits at wc*64 + nh*32 + (j&1)*16 = wc*64 + j*16
+        const int n0 = tn * 256 + wc * 64 + pchunk * 4;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        bool nv[4];
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-            const int n0 = tn * 256 + wc * 64 + nh * 32 + pchunk * 4;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            bool nv[4];
+        for (int r = 0; r < 4; ++r) nv[r] = interior || n0 + r < p.n_valid;
+        if (EPI != KZV_EPI_DGELU && p.bias) {                 // before any store (a later load could only be waited for with them)
+            if constexpr (interior) { const float4 t = *(const float4*)(p.bias + n0); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                nv[r] = n0 + r < p.n_valid;
-                if (EPI != KZV_EPI_DGELU && p.bias && nv[r]) b4[r] = p.bias[n0 + r];
+                for (int r = 0; r < 4; ++r) if (nv[r]) b4[r] = p.bias[n0 + r];
             }
+        }
+        auto block_loads = [&](int i, float4 (&r4)[4], uint2 (&u2)[4]) {
+            const int m0 = tm * 256 + wr * 128 + i * 16;
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + q * 4 + prow;
+                if (EPI == KZV_EPI_RESID) r4[q] = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
+                if (EPI == KZV_EPI_DGELU) u2[q] = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
+            }
+        };
+        // interior tiles: branch-free (counted vmcnt; see gemm_nt256.hip), the residual / pre-activation loads running
+        // LOOK row blocks ahead of their use; edge tiles: guarded, row by row
+        constexpr int LOOK = 4;
+        float4 r4[8][4]; uint2 u2[8][4];
+        if constexpr (interior) {
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int m0 = tm * 256 + wr * 128 + mh * 64 + half * 32;
-                    float4 r4[4]; uint2 u2[4];
-                    if (n0 < p.N) {
+            for (int i = 0; i < LOOK; ++i) block_loads(i, r4[i], u2[i]);
+        }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int m = m0 + q * 8 + prow;
-                            if (EPI == KZV_EPI_RESID) r4[q] = m < p.M ? *(const float4*)(p.resid + (int64_t)m * p.ldr + n0) : make_float4(0, 0, 0, 0);
-                            if (EPI == KZV_EPI_DGELU) u2[q] = m < p.M ? *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0) : make_uint2(0, 0);
-                        }
-                    }
+        for (int i = 0; i < 8; ++i) {                         // accumulator row block i: tile rows wr*128 + i*16 .. +15
+            const int m0 = tm * 256 + wr * 128 + i * 16;
 #pragma unroll
-                    for (int i2 = 0; i2 < 2; ++i2)
+            for (int j = 0; j < 4; ++j) {
+                const int chunk = j * 4 + g;
+                *(f32x4*)(patch + l15 * 64 + ((chunk ^ l15) << 2)) = acc[i][j];
+            }
+            if constexpr (interior) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int row = i2 * 16 + l15, chunk = j * 4 + g;
-                            *(f32x4*)(patch + row * 32 + ((chunk ^ (row & 7)) << 2)) = acc[mh * 4 + half * 2 + i2][nh * 2 + j];
-                        }
-                    if (n0 < p.N) {
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 4 + prow;
+                    const f32x4 a4 = *(const f32x4*)(patch + row * 64 + ((pchunk ^ row) << 2));
+                    float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
+                    nt_emit<EPI>(p, m0 + row, n0, v, r4[i][q], u2[i][q]);
+                }
+                if (i + LOOK < 8) block_loads(i + LOOK, r4[i + LOOK], u2[i + LOOK]);
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 4 + prow;
+                    const int m = m0 + row;
+                    const f32x4 a4 = *(const f32x4*)(patch + row * 64 + ((pchunk ^ row) << 2));
+                    if (m < p.M && n0 < p.N) {
+                        float4 e4 = make_float4(0, 0, 0, 0); uint2 eu = make_uint2(0, 0);
+                        if (EPI == KZV_EPI_RESID) e4 = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
+                        if (EPI == KZV_EPI_DGELU) eu = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
+                        float v[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int row = q * 8 + prow;
-                            const int m = m0 + row;
-                            const f32x4 a4 = *(const f32x4*)(patch + row * 32 + ((pchunk ^ (row & 7)) << 2));
-                            if (m >= p.M) continue;
-                            float v[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = nv[r] ? a4[r] + b4[r] : 0.f;
-                            nt_emit<EPI>(p, m, n0, v, r4[q], u2[q]);
-                        }
+                        for (int r = 0; r < 4; ++r) v[r] = nv[r] ? a4[r] + b4[r] : 0.f;
+                        nt_emit<EPI>(p, m, n0, v, e4, eu);
                     }
                 }
+            }
         }
     };
 
@@ -251,6 +271,15 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // waves 4..7 run one barrier interval behind
     bool credit = false;                            // previous drain was of an interior tile
+#ifdef KZV_STAMPS
+    // per-block stamps: [blockIdx][16]: start, then (K loop end, drain end) per tile
+    unsigned long long* stp = (EPI == KZV_EPI_BF16 && tid == 0) ? (unsigned long long*)p.aux + blockIdx.x * 16 : nullptr;
+    int stk = 0;
+#define KZV_STAMP() do { if (stp) stp[stk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KZV_STAMP() do {} while (0)
+#endif
+    KZV_STAMP();
     for (int seq = 0; ; ++seq) {
         const int id = seq * G + vblk;
         if (id >= tiles) break;
@@ -259,12 +288,19 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
         // nk is even (launcher): every tile starts on ring buffer 0, so the two K-tile bodies alternate statically
         // (selecting the body by a run-time parity made hipcc spill half the accumulators)
         for (int kt = 0; kt < nk; kt += 2) {
-            ktile(I0{}, credit && kt == 0);
-            ktile(I1{}, false);
+            ktile(I0{}, credit && kt == 0, false);
+            ktile(I1{}, false, kt + 2 >= nk);        // last K-tile of the tile: its A-h0/B-h0 refills wait for the drain
         }
-        drain(tm, tn);
-        credit = tm * 256 + 256 <= p.M && tn * 256 + 256 <= p.N;
+        KZV_STAMP();
+        credit = tm * 256 + 256 <= p.M && tn * 256 + 256 <= p.n_valid;     // interior tile (n_valid <= N)
+        if (credit) drain(tm, tn, std::true_type{}); else drain(tm, tn, std::false_type{});
+        // the refills deferred by the last K-tile (stream K-tile u+2 -> ring buffer 1): issued only now, so that the
+        // drain's own loads (bias, residual, pre-activation), which retire in order behind every earlier LDS-DMA,
+        // never wait on a load issued moments before
+        if (s2.valid) { stageA(s2, 1, 0); stageB(s2, 1, 0); }
+        advance(s2, 0);
         zero_acc();
+        KZV_STAMP();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
 }

@@ -64,8 +64,9 @@ def test_gemm_nt_epilogues(lib, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,nv", [(24600, 1024, 128, 1024), (24600, 1024, 320, 1000), (41216, 768, 768, 768)])
 def test_gemm_nt_large_shapes_take_the_256x256_kernel(lib, M, N, K, nv):
-    """>= 384 tiles of 256x256 -> gemm_nt256.hip (eight-phase schedule): ragged M, odd and minimal K-tile counts,
-    n_valid < N (clamped B rows, zeroed columns), all epilogue families."""
+    """>= 384 tiles of 256x256 -> the eight-phase kernels (persistent gemm_nt256p.hip for an even K-tile count and
+    one-store epilogues, else gemm_nt256.hip): ragged M, odd and minimal K-tile counts, n_valid < N (clamped B rows,
+    zeroed columns), all epilogue families."""
     torch.manual_seed(K)
     A = torch.randn(M, K, device=DEV).bfloat16()
     B = (torch.randn(nv, K, device=DEV) * 0.1).bfloat16()
