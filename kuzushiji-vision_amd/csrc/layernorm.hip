@@ -5,7 +5,9 @@
 //
 // HBM-bound: forward reads x once (row kept in registers), writes bf16 (+ optional fp32);
 // backward reads dy + x once, writes dx once; gamma/beta gradients are reduced per workgroup in
-// registers/LDS and leave with one float atomic per column per workgroup.
+// registers/LDS and leave with one float atomic per column per workgroup into one of LN_SLOTS partial rows
+// (644 workgroups adding to the SAME 1.5k addresses serialised on them: 122 -> 76 us at [41216, 768]), which a
+// tiny second kernel folds into dgamma / dbeta.
 //
 // Row remap (`seq`, `drop_first`): the encoder's final LN output drops the CLS token
 // (trocr_model.py:200), so output row = row - row/seq - 1 and rows with row % seq == 0 are skipped.
@@ -13,6 +15,7 @@
 #include "../../include/kzv.h"
 #include "kzv_host.h"
 #include "kzv_kernels.h"
+#include <mutex>
 
 namespace {
 
@@ -80,9 +83,12 @@ struct LnBwd {
     int rows, H, seq, drop_first, dy_f32, accumulate;
     unsigned thr16; float inv_keep; unsigned key;
     bf16_t* out16; unsigned o_thr16; float o_inv_keep; unsigned o_key;   // optional: bf16 copy of the TOTAL dx, dropout-masked
+    float* partial;                      // [LN_SLOTS][2][H] gamma/beta partial sums (zero on entry, zeroed again by the reduce kernel)
 };
 
-constexpr int BWD_ROWS = 64;  // rows per workgroup (4 waves x 16): 32 rows -> +15 % time (gamma/beta atomics on 1.5k addresses contend), 128 -> too few workgroups
+constexpr int LN_SLOTS = 32;
+
+constexpr int BWD_ROWS = 64;  // rows per workgroup (4 waves x 16)
 
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
@@ -179,9 +185,139 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { a += sf[(ww * 2) * p.H + col]; b += sf[(ww * 2 + 1) * p.H + col]; }
-        atomicAdd(p.dgamma + col, a);
-        atomicAdd(p.dbeta + col, b);
+        float* slot = p.partial + (size_t)(blockIdx.x % LN_SLOTS) * 2 * p.H;
+        atomicAdd(slot + col, a);
+        atomicAdd(slot + p.H + col, b);
     }
+}
+
+// Pipelined variant for H = NC*256 exactly (no lane guards), dy type and accumulate mode fixed at compile time: the
+// row loop is straight-line, so hipcc counts its vmcnt waits, and the loads of row r+1 are in flight while row r is
+// reduced and stored (two rows of latency overlap per wave instead of one).
+template <int NC, bool DYF32, bool ACC>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const LnBwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int nc = NC * 64;
+    float4 dg[NC], db[NC], gmr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        dg[c] = make_float4(0, 0, 0, 0); db[c] = make_float4(0, 0, 0, 0);
+        gmr[c] = ((const float4*)p.gamma)[lane + c * 64];
+    }
+    const float invH = 1.f / (float)p.H;
+    const int row_base = blockIdx.x * BWD_ROWS + w;               // this wave: rows row_base + 4*rr
+    const int n = min(BWD_ROWS / 4, (p.rows - row_base + 3) / 4); // valid rows of this wave (wave-uniform, may be <= 0)
+
+    struct Buf { float4 x[NC], prev[NC]; float4 d32[NC]; uint2 d16[NC]; float mean, rstd; };
+    auto load = [&](Buf& b, int rr) {
+        const int row = row_base + 4 * rr;
+        const int drow = p.drop_first ? max(row - row / p.seq - 1, 0) : row;
+        const float4* xr = (const float4*)(p.x + (int64_t)row * p.H);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = lane + c * 64;
+            b.x[c] = xr[i];
+            if (ACC) b.prev[c] = ((const float4*)(p.dx + (int64_t)row * p.H))[i];
+            if (DYF32) b.d32[c] = ((const float4*)((const float*)p.dy + (int64_t)drow * p.H))[i];
+            else b.d16[c] = ((const uint2*)((const bf16_t*)p.dy + (int64_t)drow * p.H))[i];
+        }
+        b.mean = p.stats[2 * row]; b.rstd = p.stats[2 * row + 1];
+    };
+    auto compute = [&](const Buf& b, int rr) {
+        const int row = row_base + 4 * rr;
+        const bool has_dy = !(p.drop_first && row % p.seq == 0);
+        const int drow = p.drop_first ? max(row - row / p.seq - 1, 0) : row;
+        const float mean = b.mean, rstd = b.rstd;
+        float4 xh[NC], gy[NC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = lane + c * 64;
+            float4 d;
+            if (DYF32) d = b.d32[c];
+            else d = make_float4(bf2f(b.d16[c].x & 0xffff), bf2f(b.d16[c].x >> 16), bf2f(b.d16[c].y & 0xffff), bf2f(b.d16[c].y >> 16));
+            if (!has_dy) d = make_float4(0, 0, 0, 0);
+            if (p.thr16) {
+                const unsigned e = (unsigned)drow * (unsigned)p.H + 4u * i;
+                const unsigned b0 = drop_bits(p.key, e >> 1), b1 = drop_bits(p.key, (e >> 1) + 1);
+                d.x *= drop_keep(b0, 0, p.thr16, p.inv_keep); d.y *= drop_keep(b0, 1, p.thr16, p.inv_keep);
+                d.z *= drop_keep(b1, 0, p.thr16, p.inv_keep); d.w *= drop_keep(b1, 1, p.thr16, p.inv_keep);
+            }
+            const float4 xv = b.x[c], gm = gmr[c];
+            xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            gy[c] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+            s1 += gy[c].x + gy[c].y + gy[c].z + gy[c].w;
+            s2 += gy[c].x * xh[c].x + gy[c].y * xh[c].y + gy[c].z * xh[c].z + gy[c].w * xh[c].w;
+            dg[c].x += d.x * xh[c].x; dg[c].y += d.y * xh[c].y; dg[c].z += d.z * xh[c].z; dg[c].w += d.w * xh[c].w;
+            db[c].x += d.x; db[c].y += d.y; db[c].z += d.z; db[c].w += d.w;
+        }
+        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+        float4* dxr = (float4*)(p.dx + (int64_t)row * p.H);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = lane + c * 64;
+            float4 o = make_float4(rstd * (gy[c].x - m1 - xh[c].x * m2), rstd * (gy[c].y - m1 - xh[c].y * m2),
+                                   rstd * (gy[c].z - m1 - xh[c].z * m2), rstd * (gy[c].w - m1 - xh[c].w * m2));
+            if (ACC) { o.x += b.prev[c].x; o.y += b.prev[c].y; o.z += b.prev[c].z; o.w += b.prev[c].w; }
+            dxr[i] = o;
+            if (p.out16) {
+                if (p.o_thr16) {
+                    const unsigned e = (unsigned)row * (unsigned)p.H + 4u * i;
+                    const unsigned b0 = drop_bits(p.o_key, e >> 1), b1 = drop_bits(p.o_key, (e >> 1) + 1);
+                    o.x *= drop_keep(b0, 0, p.o_thr16, p.o_inv_keep); o.y *= drop_keep(b0, 1, p.o_thr16, p.o_inv_keep);
+                    o.z *= drop_keep(b1, 0, p.o_thr16, p.o_inv_keep); o.w *= drop_keep(b1, 1, p.o_thr16, p.o_inv_keep);
+                }
+                ((uint2*)(p.out16 + (int64_t)row * p.H))[i] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+            }
+        }
+    };
+    if (n > 0) {
+        Buf b0, b1;
+        load(b0, 0);
+        for (int rr = 0; rr < n; rr += 2) {
+            load(b1, min(rr + 1, n - 1));        // past the end: re-load the last row (keeps the loop body branch-free)
+            compute(b0, rr);
+            load(b0, min(rr + 2, n - 1));
+            if (rr + 1 < n) compute(b1, rr + 1);
+        }
+    }
+    float4* sg = (float4*)smem + (w * 2) * nc;
+    float4* sb = sg + nc;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { sg[lane + c * 64] = dg[c]; sb[lane + c * 64] = db[c]; }
+    __syncthreads();
+    const float* sf = (const float*)smem;
+    float* slot = p.partial + (size_t)(blockIdx.x % LN_SLOTS) * 2 * p.H;
+    for (int col = threadIdx.x; col < p.H; col += 256) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { a += sf[(ww * 2) * p.H + col]; b += sf[(ww * 2 + 1) * p.H + col]; }
+        atomicAdd(slot + col, a);
+        atomicAdd(slot + p.H + col, b);
+    }
+}
+
+// dgamma / dbeta += sum over the LN_SLOTS partial rows; the partials are left zeroed for the next call.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(float* partial, float* dgamma, float* dbeta, int H) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= 2 * H) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < LN_SLOTS; ++k) { s += partial[(size_t)k * 2 * H + col]; partial[(size_t)k * 2 * H + col] = 0.f; }
+    float* out = col < H ? dgamma + col : dbeta + (col - H);
+    *out += s;
+}
+
+float* ln_partials() {          // one zeroed [LN_SLOTS][2][2048] buffer per process (calls are stream-ordered)
+    static float* buf = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* q = nullptr;
+        const size_t bytes = (size_t)LN_SLOTS * 2 * MAXC * 256 * sizeof(float);
+        if (hipMalloc(&q, bytes) == hipSuccess && hipMemset(q, 0, bytes) == hipSuccess) buf = (float*)q;
+    });
+    return buf;
 }
 
 }  // namespace
@@ -208,17 +344,31 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || rows <= 0) return kzv_fail(KZV_E_ARG, "layernorm_bwd: null/empty");
     if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
     LnBwd p{dy, x, stats, gamma, dx, dgamma, dbeta, rows, H, seq > 0 ? seq : 1, drop_first, dy_is_f32, accumulate_dx, 0, 1.f, drop_key,
-            out16, 0, 1.f, out_drop_key};
+            out16, 0, 1.f, out_drop_key, nullptr};
     kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
     kzv_drop_params(out_drop_p, &p.o_thr16, &p.o_inv_keep);
     const int ncl = (H / 4 + 63) / 64;
     const dim3 grid((rows + BWD_ROWS - 1) / BWD_ROWS);
     const size_t lds = 8 * H * sizeof(float);
-    if (ncl <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), lds, s, p);
+    p.partial = ln_partials();
+    if (!p.partial) return kzv_fail(KZV_E_HIP, "layernorm_bwd: partial-sum buffer unavailable");
+    const bool fast = H == ncl * 256 && (ncl == 1 || ncl == 3);
+#define KZV_LN_FAST(NC)                                                                                       \
+    do {                                                                                                      \
+        if (dy_is_f32) { if (accumulate_dx) hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, true, true>), grid, dim3(256), lds, s, p);   \
+                         else hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, true, false>), grid, dim3(256), lds, s, p); }              \
+        else { if (accumulate_dx) hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, false, true>), grid, dim3(256), lds, s, p);            \
+               else hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, false, false>), grid, dim3(256), lds, s, p); }                       \
+    } while (0)
+    if (fast && ncl == 1) KZV_LN_FAST(1);
+    else if (fast && ncl == 3) KZV_LN_FAST(3);
+    else if (ncl <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), lds, s, p);
     else if (ncl == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), lds, s, p);
     else if (ncl == 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, dim3(256), lds, s, p);
     else if (ncl == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), lds, s, p);
+#undef KZV_LN_FAST
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, s, p.partial, dgamma, dbeta, H);
     return kzv_check_launch("layernorm_bwd");
 }
 
