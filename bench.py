@@ -132,13 +132,27 @@ def main():
     for i in range(args.warmup):
         stepper.step(batch, i)
     barrier()
-    L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
+    # Timed region: HIP events bracket every launch of the reported kernel family only (each bracket costs ~2 us of
+    # stream time; gemm_tn / attention are measured in one extra, untimed step below).
+    events = not os.environ.get("KZV_BENCH_NO_EVENTS")     # dev knob: step time without any per-launch events
+    if events:
+        L.check(lib.kzv_prof_select(1 << 0), "prof_select")
+        L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = stepper.step(batch, i)
     barrier()
     dt = time.perf_counter() - t0
     L.check(lib.kzv_prof_enable(0, 0), "prof_disable")
+    nt_ms, nt_fl, nt_n = C.c_double(), C.c_double(), C.c_int64()
+    L.check(lib.kzv_prof_collect(0, C.byref(nt_ms), C.byref(nt_fl), C.byref(nt_n)), "prof_collect")
+    if events:                                             # untimed: one more step for the other kernel families
+        L.check(lib.kzv_prof_select((1 << 1) | (1 << 2) | (1 << 3)), "prof_select")
+        L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
+        stepper.step(batch, args.steps)
+        barrier()
+        L.check(lib.kzv_prof_enable(0, 0), "prof_disable")
+        L.check(lib.kzv_prof_select(0xffffffff), "prof_select")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -153,15 +167,15 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         T = args.label_len - 1
-        ms, fl, n = collect(0)
+        ms, fl, n = nt_ms.value, nt_fl.value, nt_n.value
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         t_act = getattr(model, "last_active_length", T)     # decoder positions actually computed (trailing all-pad columns trimmed)
         step_flops = train_flops_per_image(cfg, t_act) * args.batch
         others = {}
         for kind, name in ((1, "gemm_tn_kernel"), (2, "attn_fwd_kernel"), (3, "attn_bwd_kernel")):
             m2, f2, n2 = collect(kind)
-            others[name] = {"ms_per_step": m2 / args.steps, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0,
-                            "launches_per_step": n2 / args.steps}
+            others[name] = {"ms_per_step": m2, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0,
+                            "launches_per_step": n2, "measured": "one extra step outside the timed region"}
         DECPOS = (f"{t_act} of {T} computed: columns that are padding in every sample of the batch are skipped (exact: masked "
                   "keys, ignored targets); labels hold U{8..60} characters (BASELINE.md section 4)")
         traffic = None

@@ -168,8 +168,11 @@ int kzv_attn_bwd(const kzv_attn_args* a, void* stream);
 /* ------------------------------------------------------------- measurement hooks (bench.py roofline leg)
  * When enabled, every launch of the hot kernels is bracketed by HIP events on its own stream.
  * kind: 0 gemm_nt, 1 gemm_tn, 2 attn_fwd, 3 attn_bwd.  work = algorithmic FLOPs (2*M*N*K; 4*B*h*Sq*Sk*64 /
- * 10*B*h*Sq*Sk*64 for attention fwd / bwd).  Collect after synchronising the stream. */
+ * 10*B*h*Sq*Sk*64 for attention fwd / bwd).  Collect after synchronising the stream.
+ * kzv_prof_select restricts recording to the kinds in `kind_mask` (bit k = kind k; default all): every bracketed
+ * launch costs ~2 us of stream time, so the timed region records only the kernel it reports. */
 int kzv_prof_enable(int on, int capacity);
+int kzv_prof_select(unsigned kind_mask);
 int kzv_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches);
 uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
 

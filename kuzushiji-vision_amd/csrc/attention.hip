@@ -83,16 +83,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     stage_image<SP, 4>(Ks, Kb, p.ldk, p.Sk, p.zero16, w, lane);
     stage_image<SP, 4>(Vs, Vb, p.ldv, p.Sk, p.zero16, w, lane);
     for (int i = tid; i < SP; i += 256) kvalid[i] = i < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + i] != p.pad_id);
+    // every query fragment this wave will need, requested while the K/V images are still in flight (one exposed
+    // memory latency per workgroup instead of one per query tile)
+    constexpr int QI = (KT + 3) / 4;
+    const int nkt = (p.Sk + 15) >> 4, nqt = (p.Sq + 15) >> 4;
+    bf16x8 qf[QI][2];
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int qc = min((w + 4 * it) * 16 + l15, p.Sq - 1);
+        const bf16_t* qrow = p.Q + ((int64_t)b * p.Sq + qc) * p.ldq + h * 64 + 8 * g;
+        qf[it][0] = *(const bf16x8*)qrow; qf[it][1] = *(const bf16x8*)(qrow + 32);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nkt = (p.Sk + 15) >> 4, nqt = (p.Sq + 15) >> 4;
     const float sc = p.scale * LOG2E;
-    for (int qt = w; qt < nqt; qt += 4) {
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int qt = w + 4 * it;
+        if (qt >= nqt) break;
         const int q = qt * 16 + l15;
-        const int qc = min(q, p.Sq - 1);
-        const bf16_t* qrow = p.Q + ((int64_t)b * p.Sq + qc) * p.ldq + h * 64 + 8 * g;
-        const bf16x8 q0 = *(const bf16x8*)qrow, q1 = *(const bf16x8*)(qrow + 32);
+        const bf16x8 q0 = qf[it][0], q1 = qf[it][1];
         const int nk = MODE == 1 ? min(nkt, qt + 1) : nkt;   // causal: key tiles above the diagonal are empty
         f32x4 s[KT];
         float mx = -INFINITY;

@@ -57,10 +57,11 @@ struct ProfRec { hipEvent_t a, b; int kind; double work; };
 std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
+unsigned g_prof_mask = ~0u;
 }  // namespace
 
 KzvProfScope::KzvProfScope(int kind, double work, hipStream_t stream) : slot(-1), s(stream) {
-    if (!g_prof_on || g_prof_used >= g_prof.size()) return;
+    if (!g_prof_on || !((g_prof_mask >> kind) & 1u) || g_prof_used >= g_prof.size()) return;
     slot = (int)g_prof_used++;
     g_prof[slot].kind = kind; g_prof[slot].work = work;
     (void)hipEventRecord(g_prof[slot].a, s);
@@ -73,7 +74,7 @@ extern "C" int kzv_prof_enable(int on, int capacity) {
     if (on) {
         while ((int)g_prof.size() < capacity) {
             ProfRec r{};
-            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return kzv_fail(KZV_E_HIP, "prof: event create");
+            if (hipEventCreateWithFlags(&r.a, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&r.b, hipEventDisableSystemFence) != hipSuccess) return kzv_fail(KZV_E_HIP, "prof: event create");
             g_prof.push_back(r);
         }
         g_prof_used = 0;
@@ -81,6 +82,8 @@ extern "C" int kzv_prof_enable(int on, int capacity) {
     g_prof_on = on != 0;
     return KZV_OK;
 }
+
+extern "C" int kzv_prof_select(unsigned kind_mask) { g_prof_mask = kind_mask; return KZV_OK; }
 
 // Sums the recorded launches of `kind` (call after the stream is synchronised): total ms, total work units
 // (FLOPs), launch count.  Does not reset; kzv_prof_enable(1, n) starts a new recording.
