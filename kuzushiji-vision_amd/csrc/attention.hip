@@ -70,14 +70,24 @@ __device__ __forceinline__ float keep_of(const AttnP& p, unsigned e) {
 }
 
 // ================================================================================================ forward
+// launch bounds = the occupancy the LDS images allow anyway (3 workgroups per CU at 192 key rows, 2 at 288): with the
+// default target hipcc squeezed the kernel into 112 VGPRs and spent ~45 % of its VALU slots on v_accvgpr moves
 template <int MODE, int KT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const AttnP p) {
     constexpr int SP = KT * 16, IMG = SP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem; char* Vs = smem + IMG;
     int* kvalid = (int*)(smem + 2 * IMG);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
+#ifdef KZV_STAMPS      // diagnostic build: workgroup timeline of a few blocks into the (unused in forward) dQ buffer
+    unsigned long long* stp = (p.dQ && (blockIdx.x % 257) == 0 && tid == 0) ? (unsigned long long*)p.dQ + (blockIdx.x / 257) * 8 : nullptr;
+    int stk = 0;
+#define KZV_ASTAMP() do { if (stp) stp[stk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KZV_ASTAMP() do {} while (0)
+#endif
+    KZV_ASTAMP();
     const bf16_t* Kb = p.K + (int64_t)b * p.Sk * p.ldk + h * 64;
     const bf16_t* Vb = p.V + (int64_t)b * p.Sk * p.ldv + h * 64;
     stage_image<SP, 4>(Ks, Kb, p.ldk, p.Sk, p.zero16, w, lane);
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    KZV_ASTAMP();
 
     const float sc = p.scale * LOG2E;
 #pragma unroll
@@ -105,62 +116,71 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
         const int q = qt * 16 + l15;
         const bf16x8 q0 = qf[it][0], q1 = qf[it][1];
         const int nk = MODE == 1 ? min(nkt, qt + 1) : nkt;   // causal: key tiles above the diagonal are empty
+        // Unmasked attention (MODE 0) walks ALL KT key tiles of the LDS image (rows past Sk are zero and masked: <= 1 tile
+        // of waste at 161 tokens) so that the tile loops carry no branches; the causal mode skips tiles above the diagonal.
+        // The softmax / dropout arithmetic below is what bounds this kernel (VALU, not MFMA or HBM), so it is kept lean:
+        // masks only where a key can be invalid, the 1/sqrt(d)*log2(e) scale folded into the exponent's FMA, the raw
+        // v_exp_f32, and 1/sum * 1/keep folded into the dropout select.
         f32x4 s[KT];
-        float mx = -INFINITY;
+        float mx = -INFINITY;                                 // max of the RAW scores (scale > 0 keeps the order)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kt < nk) {
+            if (MODE == 0 || kt < nk) {
                 const int krow = kt * 16 + l15;
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, krow, g), q0, s[kt], 0, 0, 0);
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, krow, 4 + g), q1, s[kt], 0, 0, 0);
+                if (MODE == 1 || kt >= nkt - 1) {             // unmasked attention: only key tiles from the last valid one on can run past Sk
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * g + r;
-                    const bool ok = MODE == 0 ? key < p.Sk : (kvalid[key] && key <= q);
-                    s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
-                    mx = fmaxf(mx, s[kt][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + 4 * g + r;
+                        const bool ok = MODE == 0 ? key < p.Sk : (kvalid[key] && key <= q);
+                        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const bool dead = mx == -INFINITY;                    // fully masked row -> zeros, LSE = +inf
-        const float mref = dead ? 0.f : mx;
+        const float mref = dead ? 0.f : mx * sc;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
-            if (kt < nk) {
+            if (MODE == 0 || kt < nk) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[kt][r] = exp2f(s[kt][r] - mref); sum += s[kt][r]; }
+                for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, -mref)); sum += s[kt][r]; }
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = dead ? 0.f : 1.f / sum;
         if (p.LSE && g == 0 && q < p.Sq)
-            p.LSE[((int64_t)b * p.heads + h) * p.Sq + q] = dead ? INFINITY : (mx + log2f(sum)) * (1.f / LOG2E);
+            p.LSE[((int64_t)b * p.heads + h) * p.Sq + q] = dead ? INFINITY : (mx * sc + log2f(sum)) * (1.f / LOG2E);
         // dropout element index = (row of P) * Sk_even + key: the row base is even, so this lane's 4 consecutive keys
         // are exactly two hash pairs (2 hashes per 4 probabilities instead of 4)
         const unsigned ebase = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1);
+        const float keepv = inv * p.inv_keep;                 // value of a kept probability's multiplier
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
-            if (kt < nk) {
-                float k4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MODE == 0 || kt < nk) {
                 if (p.thr16) {
                     const unsigned pr = (ebase + kt * 16 + 4 * g) >> 1;
                     const unsigned b0 = drop_bits(p.key, pr), b1 = drop_bits(p.key, pr + 1);
-                    k4[0] = drop_keep(b0, 0, p.thr16, p.inv_keep); k4[1] = drop_keep(b0, 1, p.thr16, p.inv_keep);
-                    k4[2] = drop_keep(b1, 0, p.thr16, p.inv_keep); k4[3] = drop_keep(b1, 1, p.thr16, p.inv_keep);
-                }
+                    s[kt][0] *= (b0 & 0xffffu) >= p.thr16 ? keepv : 0.f; s[kt][1] *= (b0 >> 16) >= p.thr16 ? keepv : 0.f;
+                    s[kt][2] *= (b1 & 0xffffu) >= p.thr16 ? keepv : 0.f; s[kt][3] *= (b1 >> 16) >= p.thr16 ? keepv : 0.f;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] = s[kt][r] * inv * k4[r];
+                    for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+                }
             }
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kp = 0; kp < KT / 2; ++kp) {
-            if (2 * kp < nk) {
+            if (MODE == 0 || 2 * kp < nk) {
                 const bf16x8 pf = pack8((const float*)&s[2 * kp], (const float*)&s[2 * kp + 1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -175,6 +195,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             for (int dt = 0; dt < 4; ++dt)
                 *(uint2*)(orow + dt * 16) = make_uint2(pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3]));
         }
+        KZV_ASTAMP();
     }
 }
 
@@ -210,8 +231,16 @@ __device__ __forceinline__ void stage_image_asm(char* img, const bf16_t* src, in
     }
 }
 
+#ifdef KZV_STAMPS
+__device__ unsigned long long kzv_bwd_stamps[64];
+#define KZV_BSTAMP() do { if (blockIdx.x == 771 && threadIdx.x == 0 && bsk < 64) kzv_bwd_stamps[bsk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KZV_BSTAMP() do {} while (0)
+#endif
 template <int MODE, int KT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
+    [[maybe_unused]] int bsk = 0;
+    KZV_BSTAMP();
     constexpr int SP = KT * 16, IMG = SP * 128, DS_STRIDE = SP * 2 + 16, DS_BYTES = 32 * DS_STRIDE;
     constexpr int NT = NW * 64, TPW = (KT + NW - 1) / NW, TB = 8 / NW;   // threads, key tiles per wave, dQ tiles per wave
     static_assert(TPW <= 3, "dK/dV accumulators of more than 3 key tiles per wave do not fit the register file");
@@ -248,6 +277,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
     for (int i = tid; i < DS_BYTES / 16; i += NT) ((uint4*)dS)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    KZV_BSTAMP();
 
     const int nkt = (p.Sk + 15) >> 4, nqb = (p.Sq + 31) >> 5;
     const float sc = p.scale * LOG2E;
@@ -298,13 +328,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
                 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, 4 + g), k1, S, 0, 0, 0);
                 dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, g), v0, dP, 0, 0, 0);
                 dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, 4 + g), v1, dP, 0, 0, 0);
+                // dropout bits: a hash covers the key PAIR (key & ~1, key | 1) of one query row, and this lane's neighbour
+                // (l15 ^ 1) needs the same four (row, pair) hashes: each computes two rows and they swap through DPP
+                unsigned hb[4] = {0u, 0u, 0u, 0u};
+                if (p.thr16) {
+                    const int par = l15 & 1;
+                    unsigned own[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = qb * 32 + t2 * 16 + 4 * g + 2 * par + u;
+                        const unsigned e = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1) + (unsigned)key;
+                        own[u] = drop_bits(p.key, e >> 1);
+                    }
+                    const unsigned n0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own[0], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own[1], 0xB1, 0xF, 0xF, true);
+                    hb[0] = par ? n0 : own[0]; hb[1] = par ? n1 : own[1];
+                    hb[2] = par ? own[0] : n0; hb[3] = par ? own[1] : n1;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = qb * 32 + t2 * 16 + 4 * g + r;
                     const bool ok = kok && (MODE == 0 || key <= q);
                     float pr = ok ? __builtin_amdgcn_exp2f(S[r] * sc - lq[t2 * 4 + r]) : 0.f;      // lse = +inf for q >= Sq / dead rows
                     float kp = 1.f;
-                    if (p.thr16) kp = keep_of(p, (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1) + key);
+                    if (p.thr16) kp = drop_keep(hb[r], key & 1, p.thr16, p.inv_keep);
                     pd[t2 * 4 + r] = pr * kp;
                     ds[t2 * 4 + r] = pr * (dP[r] * kp - dq8[t2 * 4 + r]);
                     *(bf16_t*)(dS + (t2 * 16 + 4 * g + r) * DS_STRIDE + key * 2) = f2bf(ds[t2 * 4 + r]);
@@ -317,7 +364,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
                 dk[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt[dt], df, dk[a][dt], 0, 0, 0);
             }
         }
+        KZV_BSTAMP();
         __syncthreads();
+        KZV_BSTAMP();
         // ---------------- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for this 32-query slab ----
         {
             const int t2 = w / (NW / 2), dt0 = (w % (NW / 2)) * TB;
@@ -336,6 +385,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
                     acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[u], 0, 0, 0);
                 }
             }
+            // The next slab (this wave's pieces, issued a whole block ago) has landed.  The wait sits BEFORE the dQ
+            // stores: vmcnt retires in issue order, so after them it would also wait for stores issued a moment ago.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (q < p.Sq) {
                 bf16_t* row = p.dQ + ((int64_t)b * p.Sq + q) * p.ldq + h * 64 + 4 * g;
 #pragma unroll
@@ -346,9 +398,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
                 }
             }
         }
-        // the next slab (this wave's pieces) has landed; the barrier publishes everyone's pieces and frees dS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        KZV_BSTAMP();
+        __syncthreads();          // publishes everyone's slab pieces and frees dS
+        KZV_BSTAMP();
     }
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
@@ -387,6 +439,12 @@ int fill(AttnP& p, const kzv_attn_args* a, bool bwd) {
 }
 
 }  // namespace
+
+#ifdef KZV_STAMPS
+extern "C" int kzv_debug_bwd_stamps(unsigned long long* host64) {
+    return hipMemcpyFromSymbol(host64, HIP_SYMBOL(kzv_bwd_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
     AttnP p;
