@@ -367,13 +367,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                 tile[n * 128 + ((((k >> 2) ^ (n & 31)) << 2) | (k & 3))] = acc[i][j][r];
             }
     __syncthreads();
-    for (int it = 0; it < 64; ++it) {
-        const int n = w * 32 + (it >> 1), k = (it & 1) * 64 + lane;
-        const int gn = tnb * 128 + n, gk = tkb * 128 + k;
-        if (gn < p.n_store && gk < p.K) {
-            const float v = tile[n * 128 + ((((k >> 2) ^ (n & 31)) << 2) | (k & 3))];
+    // 8 rows per batch: the LDS reads of a batch are issued together (one latency per batch, not per row), and the
+    // interior case is branch-free so the adds stream out back to back
+    const bool interior = tnb * 128 + 128 <= p.n_store && tkb * 128 + 128 <= p.K;     // wave-uniform
+    for (int it0 = 0; it0 < 64; it0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = it0 + u;
+            const int n = w * 32 + (it >> 1), k = (it & 1) * 64 + lane;
+            v[u] = tile[n * 128 + ((((k >> 2) ^ (n & 31)) << 2) | (k & 3))];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = it0 + u;
+            const int n = w * 32 + (it >> 1), k = (it & 1) * 64 + lane;
+            const int gn = tnb * 128 + n, gk = tkb * 128 + k;
             float* o = p.OUT + (int64_t)gn * p.ldo + gk;
-            if (p.splits == 1) *o += v; else atomicAdd(o, v);
+            if (interior && p.splits > 1) atomicAdd(o, v[u]);
+            else if (gn < p.n_store && gk < p.K) { if (p.splits == 1) *o += v[u]; else atomicAdd(o, v[u]); }
         }
     }
 }
