@@ -66,11 +66,14 @@ struct kzv_model {
     std::vector<DecAct> da;
     // backward scratch
     float *dx_e, *dx_d, *dsum_d;
+    bf16_t *dy_e2;           // second dy_e (overlap mode 2: the fc2 weight gradient still reads dy_e while LayerNorm-2 backward writes its output)
     bf16_t *dy_e, *dbig_e, *dh_e, *dqkv_e, *dctx_e, *dpatch, *denc_out, *denc, *dckv, *dy_d, *dbig_d, *dqkv_d, *dctx_d, *dq_d, *dhln;
     // weight-gradient GEMMs run on an internal side stream so they overlap the input-gradient chain on the
     // caller's stream (their tails and epilogues fill each other's idle workgroup slots)
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr; hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[4] = {false, false, false, false}; bool use_side = false, join_each_segment = true;
+    bool side_ok = false;    // mode 2: set only inside the encoder-layer schedule (everything else stays on the caller's stream)
+    int side_mode = 0;       // 0 off, 1 free-running wgrads, 2 wgrads only under the HBM-bound kernels (LayerNorm / attention backward)
 };
 
 namespace {
@@ -224,7 +227,7 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
     m->hd_ln = b.take<bf16_t>(Md * Hd);
     m->logits = b.take<float>(Md * m->Vp); m->dlogits = b.take<bf16_t>(Md * m->Vp);
     // backward scratch
-    m->dx_e = b.take<float>(Me * He); m->dy_e = b.take<bf16_t>(Me * He); m->dbig_e = b.take<bf16_t>(Me * Fe);
+    m->dx_e = b.take<float>(Me * He); m->dy_e = b.take<bf16_t>(Me * He); m->dy_e2 = b.take<bf16_t>(Me * He); m->dbig_e = b.take<bf16_t>(Me * Fe);
     m->dh_e = b.take<bf16_t>(Me * He); m->dqkv_e = b.take<bf16_t>(Me * 3 * He); m->dctx_e = b.take<bf16_t>(Me * He);
     m->dpatch = b.take<bf16_t>(Mp * He); m->denc_out = b.take<bf16_t>(Mp * He);
     m->denc = m->has_proj ? b.take<bf16_t>(Mp * Hd) : m->denc_out;
@@ -268,7 +271,7 @@ enum { CLS_DY = 0, CLS_DBIG = 1, CLS_DQKV = 2, CLS_MISC = 3 };
 
 int wgrad_async(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok,
                 int N, int K, int n_store, float* dbias) {
-    if (!m->use_side) return wgrad(dY, ldp, X, ldq, dW, Mtok, N, K, n_store, s, dbias);
+    if (!m->use_side || (m->side_mode == 2 && !m->side_ok)) return wgrad(dY, ldp, X, ldq, dW, Mtok, N, K, n_store, s, dbias);
     if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess)
         return kzv_fail(KZV_E_HIP, "wgrad_async: fork");
     const int rc = wgrad(dY, ldp, X, ldq, dW, Mtok, N, K, n_store, m->side, dbias);
@@ -472,6 +475,32 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     float* P = m->P; float* G = m->G;
     EncAct& a = m->ea[i];
     const EncLayerP& e = m->ep[i];
+    if (m->side_mode == 2) {
+        // Overlap mode 2: the four weight-gradient GEMMs (MFMA-bound, 710 us per layer) run on the side stream ONLY while
+        // the caller's stream runs an HBM- or issue-bound kernel (LayerNorm backward x2, attention backward: 344 us per
+        // layer); every input-gradient GEMM first joins the side stream, so the gemm_nt kernels never share the machine
+        // (their per-launch times stay what they are alone) and nothing MFMA-bound competes with anything MFMA-bound.
+        struct SideOk { kzv_model* m; ~SideOk() { m->side_ok = false; } } side_guard{m};
+        m->side_ok = true;
+        KZV_TRY(join_side(m, s));
+        KZV_TRY(gemm(m->dy_e, He, m->w_efc2[i], true, Me, Fe, He, Fe, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe));
+        KZV_TRY(gemm(m->dbig_e, Fe, m->w_efc1[i], true, Me, He, Fe, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, G + e.fc2b));
+        KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s,
+                              m->dy_e2, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
+        KZV_TRY(join_side(m, s));
+        KZV_TRY(gemm(m->dy_e2, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
+        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e2, He, a.ctx, He, G + e.ow, Me, He, He, He, G + e.ob));
+        KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
+        KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
+                     m->dqkv_e + 2 * He, c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+        KZV_TRY(join_side(m, s));
+        KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+        KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
+        KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_in, a.st1, P + e.ln1w, m->dx_e, 1, G + e.ln1w, G + e.ln1b, Me, He, 1, 0, 0.f, 0, s,
+                              i > 0 ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (i - 1) + 2)));
+        return KZV_OK;
+    }
     // x_out = x_mid + drop(fc2(gelu(fc1(LN2(x_mid)))))
     // on entry dy_e = dropout-masked bf16 copy of dx_e for this layer's fc2 site (written by the LN backward above it)
     KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, G + e.fc2b));
@@ -590,10 +619,15 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
         return kzv_fail(KZV_E_HIP, "model_bind: descriptor upload");
     if (!m->side) {
         const char* e = getenv("KZV_SIDE_STREAM");
-        // opt-in (KZV_SIDE_STREAM=1): measured +1.7 % img/s, but co-running kernels stretch each other's
-        // durations, which blurs the per-kernel roofline accounting -- off by default so profiles stay clean
-        m->use_side = e && e[0] == '1';
+        // KZV_SIDE_STREAM: 0 (default) = one stream; 1 = weight gradients free-running on a side stream: +3 % img/s
+        // (7,180 -> 7,410), but the co-running kernels stretch each other (gemm_nt family 920 -> 715 TFLOP/s per launch),
+        // so the per-kernel roofline accounting is only meaningful with it off; 2 = encoder weight gradients only under
+        // the LayerNorm / attention backward kernels, every input-gradient GEMM joining the side stream first: the 120
+        // cross-stream waits per step cost more than the overlap returns (6,400 img/s) -- kept for the record.
+        m->side_mode = (e && e[0]) ? atoi(e) : 0;
+        m->use_side = m->side_mode != 0;
         if (m->use_side) {
+            // (stream priorities make no measurable difference here: the range on this part is {0, -1})
             if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: side stream");
             if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: event");
             for (int i = 0; i < 4; ++i)
