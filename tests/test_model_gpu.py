@@ -391,3 +391,18 @@ def test_trailing_padding_trim_does_not_change_loss_or_gradients(tmp_path):
     # and against the oracle on the full length
     r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 13)), px, lab)
     assert abs(res[True][0] - r["loss"]) < 5e-3
+
+
+def test_reference_fixtures_through_the_256x256_gemm_kernels(tmp_path):
+    """The large-shape GEMM kernels (gemm_nt256p / gemm_nt256) only engage above 384 output tiles, i.e. not at fixture
+    sizes.  Re-run the reference-fixture parity tests in a child process that forces them for every K >= 128 GEMM
+    (KZV_NT256*_MIN_TILES=1): whole-model forward/backward parity then covers their ragged-M / ragged-N / clamped paths."""
+    import subprocess
+    import sys
+    env = dict(os.environ, KZV_NT256P_MIN_TILES="1", KZV_NT256_MIN_TILES="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_model_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "tiny_matches_reference_fixture or vitb_summary_matches_reference_fixture or edge_geometries", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
