@@ -18,6 +18,7 @@
 #include "../../include/kzv.h"
 #include "kzv_host.h"
 #include "gemm_nt.h"
+#include "gemm_tn.h"
 #include <cstdlib>
 
 namespace {
@@ -217,13 +218,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
 // Reduction index inside a 32-token MFMA step is permuted (element j of lane group g <-> token
 // 16*(j>>2) + 4g + (j&3)); both operands use the same permutation so the sum is unchanged, and the two
 // groups of a 32-lane half then read 8 consecutive rows -> the XOR swizzle below is conflict-free.
-struct TnParams {
-    const bf16_t* P; const bf16_t* Q; float* OUT; const void* zero16;
-    int64_t ldp, ldq, ldo;
-    int Mtok, N, K, n_store, splits, chunk;   // chunk = tokens per split (multiple of 64)
-    float* dbias;                              // optional: dbias[n] += sum_t P[t][n]  (the nn.Linear bias gradient)
-};
-
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -461,6 +455,8 @@ extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
     p.ldp = a->ldp; p.ldq = a->ldq; p.ldo = a->ldo;
     p.Mtok = a->Mtok; p.N = a->N; p.K = a->K; p.n_store = a->n_store > 0 ? a->n_store : a->N;
     p.dbias = a->dbias;
+    KzvProfScope prof(1, 2.0 * a->Mtok * p.n_store * a->K, (hipStream_t)stream);
+    if (kzv_tn256_launch(p, (hipStream_t)stream)) return kzv_check_launch("gemm_tn");     // >= 24 tiles of 256x256: eight-phase kernel
     const int tiles = ((a->N + 127) / 128) * ((a->K + 127) / 128);
     const int tok_tiles = (a->Mtok + 63) / 64;
     // Token splits: fill the 512 resident slots (256 CUs x 2 workgroups) in ONE round without overshooting
@@ -478,7 +474,6 @@ extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
     p.splits = splits; p.chunk = chunk_tiles * 64;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS); attr_done = true; }
-    KzvProfScope prof(1, 2.0 * a->Mtok * p.n_store * a->K, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), NT_LDS, (hipStream_t)stream, p);
     return kzv_check_launch("gemm_tn");
 }

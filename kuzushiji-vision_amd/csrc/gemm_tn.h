@@ -1,0 +1,14 @@
+// Shared between the two gemm_tn kernels (gemm.hip: 128x128 two-stage; gemm_tn256.hip: 256x256 eight-phase).
+#pragma once
+#include "kzv_common.h"
+
+struct TnParams {
+    const bf16_t* P; const bf16_t* Q; float* OUT; const void* zero16;
+    int64_t ldp, ldq, ldo;
+    int Mtok, N, K, n_store, splits, chunk;   // chunk = tokens per split (multiple of 64)
+    float* dbias;                              // optional: dbias[n] += sum_t P[t][n]  (the nn.Linear bias gradient)
+};
+
+// gemm_tn256.hip: returns 1 when it took the launch (p.splits / p.chunk are chosen inside), 0 when the shape is left
+// to the 128x128 kernel.
+int kzv_tn256_launch(const TnParams& p, hipStream_t s);

@@ -1,0 +1,321 @@
+// gemm_tn, 256x256 tile, eight-phase ping-pong schedule for gfx950 (MI355X).
+//
+//  OUT[n][k] += sum_t P[t][n] * Q[t][k]   (every large weight gradient dW = dY^T . X; optional dbias[n] += sum_t P[t][n])
+//
+// The schedule is gemm_nt256.hip's (read its header): one 512-thread workgroup per CU, 8 waves (2 per SIMD), wave
+// (wr, wc) owns output rows n = wr*128..+127 and columns k = wc*64..+63 (8x4 MFMA accumulators), an LDS ring of two
+// reduction stages x four 16-KiB half-tiles, one accumulator quadrant and one half-tile of LDS-DMA per phase, counted
+// `vmcnt(8)` before a barrier, the first read one phase later, waves 4..7 one barrier interval behind waves 0..3.
+// What differs is the operand geometry: the reduction index t is the ROW index of both operands (as in gemm.hip's
+// gemm_tn), so
+//   * a half-tile is 64 tokens x 128 contiguous tile columns (256-B rows = two full cache lines per DMA row):
+//     P-h{h} / Q-h{h} hold tile columns h*128 .. +127, and
+//     wave (wr, wc) owns output rows {mh*128 + wr*64 + 0..63} and columns {nh*128 + wc*32 + 0..31}, mh, nh in {0, 1};
+//     slot s of row r holds source chunk s ^ ((r & 7) << 1);
+//   * fragments come out of LDS through ds_read_b64_tr_b16 (two per fragment) with gemm_tn's permuted token mapping;
+//   * the reduction is split over token ranges (one workgroup per CU in total).  A 256x256 fp32 partial tile per
+//     workgroup is 62-66 MB per launch: as float atomics (~1 TB/s) that cost 70 us and ate the main-loop gain, so the
+//     partials are written with plain streaming stores (1-KiB row segments through LDS) into a workspace and a second
+//     small kernel folds the splits into OUT (reads 62 MB at HBM rate).
+// The launcher takes only shapes with >= 24 output tiles (qkv, fc1, fc2 of a ViT layer); everything else stays on the
+// 128x128 kernel with its atomic epilogue.
+//
+// Measured (MI355X, 41216 tokens): a reduction stage takes ~2.0 us here against 1.48 us for a K-tile of gemm_nt256 with the
+// same MFMA and LDS work and 0 bank conflicts: both operands of a weight gradient stream from HBM (nothing is reused from
+// L2 the way a weight panel is), and the 64-80 KiB of LDS-DMA the two-stage ring keeps in flight per CU is ~0.7 of what
+// that latency needs at this consumption rate.  Net against the 128x128 kernel: qkv 181 -> 176 us, fc1 224 -> 203, fc2 229 -> 197.
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "gemm_tn.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int HT_BYTES = 64 * 256;         // half-tile: 64 tokens x 128 bf16
+constexpr int BUF_BYTES = 4 * HT_BYTES;    // P-h0, P-h1, Q-h0, Q-h1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;   // 128 KiB
+constexpr int KP0 = 0, KP1 = 1, KQ0 = 2, KQ1 = 3;
+
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 0, "add the vmcnt literal");
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(const TnParams p, float* part_ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wr = w >> 2, wc = w & 3;
+    const int tilesN = (p.N + 255) / 256, tilesK = (p.K + 255) / 256;
+    const int per = tilesN * tilesK;
+    const int id = xcd_remap(blockIdx.x, per * p.splits);
+    const int split = id / per, rem = id - split * per;
+    const int tnb = rem / tilesK, tkb = rem - tnb * tilesK;
+    const int t_begin = split * p.chunk;                      // chunk and Mtok are multiples of 64 (launcher)
+    const int t_end = min(p.Mtok, t_begin + p.chunk);
+    const int nt = (t_end - t_begin) >> 6;                    // >= 2 (launcher)
+
+    // ---- LDS-DMA sources: wave w fills 1-KiB pieces w and w+8 of every half-tile (4 token rows x 256 B each) ----
+    // Columns beyond N / K are clamped to the last valid 8-column chunk: their products are never stored.
+    const char* baseP = (const char*)(p.P + (int64_t)t_begin * p.ldp);
+    const char* baseQ = (const char*)(p.Q + (int64_t)t_begin * p.ldq);
+    const int64_t stepP = 64 * p.ldp * 2, stepQ = 64 * p.ldq * 2;
+    unsigned voff[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (w + 8 * j) * 4 + (lane >> 4);
+        const int col = (((lane & 15) ^ ((r & 7) << 1))) * 8;           // first of this lane's 8 local columns
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = min(tnb * 256 + h * 128 + col, p.N - 8);
+            voff[KP0 + h][j] = (unsigned)r * (unsigned)(p.ldp * 2) + (unsigned)n * 2u;
+            const int k = min(tkb * 256 + h * 128 + col, p.K - 8);
+            voff[KQ0 + h][j] = (unsigned)r * (unsigned)(p.ldq * 2) + (unsigned)k * 2u;
+        }
+    }
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)smem) + (unsigned)w * 1024u);
+    auto stage = [&](int buf, int kind, int kt) {
+        const char* sb = kind < 2 ? baseP + (int64_t)kt * stepP : baseQ + (int64_t)kt * stepQ;
+        const unsigned d = ldsw + (unsigned)(buf * BUF_BYTES + kind * HT_BYTES);
+        glds16_s(voff[kind][0], sb, d);
+        glds16_s(voff[kind][1], sb, d + 8192u);
+    };
+
+    f32x4 acc[4][8];                                          // [k-frag][n-frag]: D rows = n (4g+r), D cols = k (l15)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposing reads (gemm.hip gemm_tn): lane supplies token row 4g + (l15>>2) [+16], columns c0 + (l15&3)*4 .. +3
+    const int trow = 4 * g + (l15 >> 2);
+    const int tsw0 = (trow & 7) << 1;
+    const int sub8 = (l15 & 1) * 8;
+    const int cq = (l15 >> 1) & 1;
+    bf16x8 fp[4][2], fq0[2][2], fq1[2][2];                    // [frag][token half ks]
+    // (the swizzle term is laundered per call: hoisted, the six XOR-ed fragment addresses per ring buffer stay live across
+    // the whole loop and push the kernel past 256 VGPRs; recomputing them is a handful of VALU ops in the load part)
+    auto readP = [&](int buf, int mh) {
+        const char* b = smem + buf * BUF_BYTES + (KP0 + mh) * HT_BYTES;
+        int tsw = tsw0;
+        asm volatile("" : "+v"(tsw));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = (ks * 32 + trow) * 256, r1 = r0 + 16 * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int chunk = (wr * 8 + j * 2 + cq) ^ tsw;
+                const bf16x4 lo = lds_tr16(b + r0 + chunk * 16 + sub8), hi = lds_tr16(b + r1 + chunk * 16 + sub8);
+                fp[j][ks] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+    };
+    auto readQ = [&](int buf, int nh, bf16x8 (&fq)[2][2]) {
+        const char* b = smem + buf * BUF_BYTES + (KQ0 + nh) * HT_BYTES;
+        int tsw = tsw0;
+        asm volatile("" : "+v"(tsw));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = (ks * 32 + trow) * 256, r1 = r0 + 16 * 256;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int chunk = (wc * 4 + i * 2 + cq) ^ tsw;
+                const bf16x4 lo = lds_tr16(b + r0 + chunk * 16 + sub8), hi = lds_tr16(b + r1 + chunk * 16 + sub8);
+                fq[i][ks] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+    };
+    auto mma = [&](int mh, int nh, const bf16x8 (&fq)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[nh * 2 + i][mh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[j][ks], fq[i][ks], acc[nh * 2 + i][mh * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // Bias gradient = column sums of P.  Each (n-tile, split) P panel is streamed by tilesK workgroups; workgroup tkb takes
+    // the stages t with t % tilesK == tkb, waves with wc == 0 only (as gemm.hip).  The A fragment of lane (g, l15) is row
+    // n = l15 of its 16-row block with 8 of the 32 tokens, so the sum is VALU work on fragments already in registers:
+    // one float per block instead of the 4-register MFMA accumulator the 128x128 kernel spends (this kernel has none left).
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    const bool bias_wave = p.dbias != nullptr && wc == 0;
+    auto bias_add = [&](int mh) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 u = __builtin_bit_cast(u32x4, fp[j][ks]);
+                float sacc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sacc += __uint_as_float(u[q] << 16) + __uint_as_float(u[q] & 0xffff0000u);
+                bsum[mh * 4 + j] += sacc;
+            }
+    };
+
+    auto ktile = [&](auto bufc, int t) {
+        constexpr int BUF = decltype(bufc)::value;
+        const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
+        const bool wb = bias_wave && (t % tilesK) == tkb;
+        // p1
+        readP(BUF, 0); readQ(BUF, 0, fq0);
+        if (s1) { stage(BUF ^ 1, KQ1, t + 1); vmcnt<8>(); } else vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        mma(0, 0, fq0);
+        if (wb) bias_add(0);
+        __builtin_amdgcn_s_barrier();
+        // p2
+        readQ(BUF, 1, fq1);
+        if (s1) { stage(BUF ^ 1, KP1, t + 1); vmcnt<8>(); } else vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        mma(0, 1, fq1);
+        __builtin_amdgcn_s_barrier();
+        // p3
+        readP(BUF, 1);
+        if (s2) stage(BUF, KP0, t + 2);
+        __builtin_amdgcn_s_barrier();
+        mma(1, 1, fq1);
+        if (wb) bias_add(1);
+        __builtin_amdgcn_s_barrier();
+        // p4
+        if (s2) { stage(BUF, KQ0, t + 2); vmcnt<8>(); } else if (s1) vmcnt<4>();
+        __builtin_amdgcn_s_barrier();
+        mma(1, 0, fq0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+    stage(0, KP0, 0); stage(0, KQ0, 0); stage(0, KQ1, 0); stage(0, KP1, 0); stage(1, KP0, 1); stage(1, KQ0, 1);
+    vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // waves 4..7 run one barrier interval behind
+    for (int t = 0; t < nt; t += 2) {
+        ktile(I0{}, t);
+        if (t + 1 < nt) ktile(I1{}, t + 1);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();     // balance the barrier count
+
+    if (bias_wave) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = tnb * 256 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + l15;
+            if (g == 0 && n < p.n_store) atomicAdd(p.dbias + n, v);
+        }
+    }
+
+    // ---- epilogue: two chunks of 128 output rows (chunk c = tile rows c*128 .. +127 = the mh == c accumulators) through LDS
+    // (fp32 [128][256], 16-B chunks XOR (row & 31)) -> this workgroup's partial tile in the workspace, one 1-KiB row
+    // per wave-instruction, streamed past L2 ----
+    float* tile = (float*)smem;
+    float* part = part_ws + (size_t)id * 65536;                       // [256][256] fp32 per workgroup (id = split * per + tile)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        __syncthreads();                           // the ring / the previous chunk is no longer being read
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ln = wr * 64 + j * 16 + 4 * g + r;                 // local row: tile row c*128 + ln
+                    const int k = (i >> 1) * 128 + wc * 32 + (i & 1) * 16 + l15;
+                    tile[ln * 256 + ((((k >> 2) ^ (ln & 31)) << 2) | (k & 3))] = acc[i][c * 4 + j][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {          // wave w: local rows w*16 .. +15
+            const int ln = w * 16 + it;
+            const f32x4 v = *(const f32x4*)(tile + ln * 256 + ((lane ^ (ln & 31)) << 2));
+            const int row = c * 128 + ln;
+            __builtin_nontemporal_store(v, (f32x4*)(part + row * 256 + lane * 4));
+        }
+    }
+}
+
+// OUT[n][k] += sum over splits of the partial tiles (4 columns per thread, one 1-KiB row segment per wave-instruction)
+__global__ __launch_bounds__(256) void gemm_tn256_fold_kernel(const float* part_ws, float* OUT, int64_t ldo, int n_store, int K,
+                                                             int tilesK, int per, int splits) {
+    const int tile = blockIdx.x >> 6;                                 // 64 workgroups per tile: 4 rows each
+    const int row = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6), k4 = (threadIdx.x & 63) * 4;
+    const int tnb = tile / tilesK, tkb = tile - tnb * tilesK;
+    const int gn = tnb * 256 + row, gk = tkb * 256 + k4;
+    if (gn >= n_store || gk >= K) return;                             // K % 4 == 0 (launcher): a 4-column group is all in or all out
+    const float* src = part_ws + ((size_t)tile * 256 + row) * 256 + k4;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int sp = 0; sp < splits; ++sp) s += __builtin_nontemporal_load((const f32x4*)(src + (size_t)sp * per * 65536));
+    f32x4* o = (f32x4*)(OUT + (int64_t)gn * ldo + gk);
+    *o += s;
+}
+
+float* tn_partials(size_t floats) {      // grow-only workspace (calls are stream-ordered; the fold kernel of a launch reads it
+    static float* buf = nullptr;         // before the next launch's partial stores, in the same stream)
+    static size_t cap = 0;
+    if (floats > cap) {
+        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        void* q = nullptr;
+        if (hipMalloc(&q, floats * sizeof(float)) != hipSuccess) return nullptr;
+        buf = (float*)q; cap = floats;
+    }
+    return buf;
+}
+
+int tn256_min_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("KZV_TN256_MIN_TILES"); v = e ? atoi(e) : 24; }
+    return v;
+}
+int device_cus() {
+    static int v = -1;
+    if (v < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        v = n;
+    }
+    return v;
+}
+
+}  // namespace
+
+int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
+    const int tiles = ((p0.N + 255) / 256) * ((p0.K + 255) / 256);
+    const int tok_tiles = p0.Mtok / 64;
+    if (tiles < tn256_min_tiles() || p0.Mtok % 64 || tok_tiles < 2 || p0.N < 8 || p0.K < 8) return 0;
+    if ((uint64_t)64 * (uint64_t)p0.ldp * 2 + (uint64_t)p0.N * 2 > 0xffffffffull || (uint64_t)64 * (uint64_t)p0.ldq * 2 + (uint64_t)p0.K * 2 > 0xffffffffull) return 0;
+    TnParams p = p0;
+    // one workgroup per CU in total; every split keeps >= 8 reduction stages (and at least 2: the prologue stages two)
+    int splits = device_cus() / tiles;
+    if (splits > tok_tiles / 8) splits = tok_tiles / 8;
+    if (splits < 1) splits = 1;
+    int chunk_tiles = (tok_tiles + splits - 1) / splits;
+    if (chunk_tiles < 2) chunk_tiles = 2;
+    splits = (tok_tiles + chunk_tiles - 1) / chunk_tiles;
+    if (tok_tiles - (splits - 1) * chunk_tiles < 2) return 0;         // a one-stage last split: leave it to the 128x128 kernel
+    p.splits = splits; p.chunk = chunk_tiles * 64;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; }
+    if (p.K % 4 || p.ldo % 4 || ((uintptr_t)p.OUT & 15)) return 0;
+    float* ws = tn_partials((size_t)tiles * splits * 65536);
+    if (!ws) return 0;
+    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * splits), dim3(512), LDS_BYTES, s, p, ws);
+    hipLaunchKernelGGL(gemm_tn256_fold_kernel, dim3(tiles * 64), dim3(256), 0, s, ws, p.OUT, p.ldo, p.n_store, p.K,
+                       (p.K + 255) / 256, tiles, splits);
+    return 1;
+}

@@ -136,6 +136,25 @@ def test_gemm_tn(lib, Mt, N, K):
     assert (db - db0 - Pm.float().sum(0)).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("Mt,N,K", [(8192, 1536, 1024), (4096, 2304, 768), (4160, 1288, 1280)])
+def test_gemm_tn_large_outputs_take_the_256x256_kernel(lib, Mt, N, K):
+    """>= 24 output tiles of 256x256 and Mtok % 64 == 0 -> gemm_tn256.hip (eight-phase schedule, token splits, atomics
+    epilogue, VALU bias sums); ragged N / K (clamped columns, guarded stores) in the last case; accumulates INTO out."""
+    torch.manual_seed(Mt + N)
+    Pm = torch.randn(Mt, N, device=DEV).bfloat16()
+    Q = torch.randn(Mt, K, device=DEV).bfloat16()
+    base = torch.randn(N, K, device=DEV)
+    out = base.clone()
+    db0 = torch.randn(N, device=DEV)
+    db = db0.clone()
+    a = L.kzv_gemm_tn_args(P=Pm.data_ptr(), ldp=N, Q=Q.data_ptr(), ldq=K, OUT=out.data_ptr(), ldo=K, Mtok=Mt, N=N, K=K, n_store=N,
+                           dbias=db.data_ptr())
+    L.check(lib.kzv_gemm_tn(C.byref(a), _st()), "gemm_tn")
+    ref = Pm.float().t() @ Q.float() + base
+    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 2e-3      # fp32 sums of 4-8k products, split + atomics
+    assert (db - db0 - Pm.float().sum(0)).abs().max().item() < 2e-3 * (Mt / 4096) ** 0.5 + 2e-3
+
+
 @pytest.mark.parametrize("rows,H", [(7, 64), (1000, 256), (333, 768), (64, 1024)])
 def test_layernorm_fwd_bwd(lib, rows, H):
     torch.manual_seed(rows)
