@@ -21,9 +21,11 @@
 // 128x128 kernel with its atomic epilogue.
 //
 // Measured (MI355X, 41216 tokens): a reduction stage takes ~2.0 us here against 1.48 us for a K-tile of gemm_nt256 with the
-// same MFMA and LDS work and 0 bank conflicts: both operands of a weight gradient stream from HBM (nothing is reused from
-// L2 the way a weight panel is), and the 64-80 KiB of LDS-DMA the two-stage ring keeps in flight per CU is ~0.7 of what
-// that latency needs at this consumption rate.  Net against the 128x128 kernel: qkv 181 -> 176 us, fc1 224 -> 203, fc2 229 -> 197.
+// same MFMA and LDS work and 0 bank conflicts (SQ_LDS_IDX_ACTIVE equal, 2.0 cycles per transposing read).  Not memory
+// latency: a 10-slot ring over all 160 KiB of LDS (every half-tile issued two whole stages ahead, vmcnt(12)) was 5 %
+// SLOWER, and contiguous vs interleaved half-tile columns made no difference.  What remains is the doubled LDS instruction
+// count of the transposing reads in the load parts.  Net against the 128x128 kernel: qkv 181 -> 176 us, fc1 224 -> 203,
+// fc2 229 -> 197 (-1 ms per training step).
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
