@@ -12,8 +12,8 @@
 //    combined with the residual or the saved pre-activation.  No workgroup barrier is involved, so the two wave groups drain half a phase apart
 //    and the next tile's loads keep landing meanwhile.
 //
-// vmcnt bookkeeping across a drain.  vmcnt counts this wave's VMEM operations in issue order (loads and stores
-// retire in order on gfx9-family parts).  A wait that must retire an LDS-DMA load issued BEFORE the drain may leave
+// vmcnt bookkeeping across a drain.  vmcnt counts this wave's VMEM operations in issue order (loads, stores, atomics
+// and LDS-DMA count together and retire in order: MI355X_MICROARCH.md, `s_waitcnt vmcnt(N)`).  A wait that must retire an LDS-DMA load issued BEFORE the drain may leave
 // outstanding every operation issued after that load: the usual 8 (four half-tiles) plus the D loads/stores of the
 // drain.  D is only credited for interior tiles, where every row and column is stored (an edge tile skips some
 // stores; crediting too few is merely conservative, crediting too many would be a race).
