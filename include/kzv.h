@@ -176,6 +176,13 @@ int kzv_prof_select(unsigned kind_mask);
 int kzv_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches);
 uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
 
+/* Data-parallel runs: the GEMM kernels that put exactly one workgroup on every CU (persistent gemm_nt256p, gemm_tn256)
+ * double their time when a concurrently running collective holds a few CUs.  With n > 0 the launchers leave n CUs
+ * free: gemm_nt falls back to the one-tile-per-workgroup kernel (its workgroups flow to whatever CUs are free) and
+ * gemm_tn256 sizes its token splits to (CUs - n) workgroups.  Default 0 (or KZV_CU_RESERVE); kzv/trainer.py sets it
+ * when world_size > 1. */
+int kzv_set_cu_reserve(int n);
+
 #ifdef __cplusplus
 }
 #endif

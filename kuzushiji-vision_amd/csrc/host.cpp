@@ -1,5 +1,6 @@
 // Error reporting, the shared zero page and dropout key/threshold helpers.
 #include "kzv_host.h"
+#include <cstdlib>
 #include "../../include/kzv.h"
 #include <cstdarg>
 #include <cstdio>
@@ -49,6 +50,18 @@ extern "C" uint32_t kzv_drop_key(uint64_t seed, uint32_t site) {
 }
 
 extern "C" const char* kzv_last_error(void) { return g_err; }
+
+// CUs the GEMM launchers leave to concurrently running collectives (see include/kzv.h)
+static int g_cu_reserve = -1;
+int kzv_cu_reserve() {
+    if (g_cu_reserve < 0) { const char* e = getenv("KZV_CU_RESERVE"); g_cu_reserve = (e && e[0]) ? atoi(e) : 0; }
+    return g_cu_reserve;
+}
+extern "C" int kzv_set_cu_reserve(int n) {
+    if (n < 0 || n > 128) return kzv_fail(KZV_E_ARG, "set_cu_reserve: 0..128");
+    g_cu_reserve = n;
+    return KZV_OK;
+}
 extern "C" int kzv_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------------ profiling

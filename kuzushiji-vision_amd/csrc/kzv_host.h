@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 int kzv_fail(int code, const char* fmt, ...);          // records message, returns code
-int kzv_check_launch(const char* what);                // hipGetLastError -> KZV_E_HIP
+int kzv_check_launch(const char* what);
+int kzv_cu_reserve();                                  // CUs left to concurrent collectives (kzv_set_cu_reserve / KZV_CU_RESERVE)                // hipGetLastError -> KZV_E_HIP
 const void* kzv_zero_page();                           // 4 KiB of device zeros (allocated once per process)
 void kzv_drop_params(float p, unsigned* thr16, float* inv_keep);
 extern "C" uint32_t kzv_drop_key(uint64_t seed, uint32_t site);

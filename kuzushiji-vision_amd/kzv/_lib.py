@@ -88,6 +88,7 @@ SYMBOLS = {
     "kzv_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "kzv_prof_select": (C.c_int, [C.c_uint]),
+    "kzv_set_cu_reserve": (C.c_int, [C.c_int]),
     "kzv_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 

@@ -37,6 +37,12 @@ def init_distributed(backend: str | None = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            # RCCL's channel workgroups sit on CUs for the whole collective; keep them few (393 MB of gradients per
+            # ~35 ms step needs little bandwidth) and tell the GEMM launchers to leave that many CUs alone, or the
+            # one-workgroup-per-CU kernels would run a second round for the workgroups that found their CU taken
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+            if os.environ.get("KZV_CU_RESERVE") is None:
+                L.check(L.load().kzv_set_cu_reserve(32), "set_cu_reserve")
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
