@@ -1,12 +1,14 @@
-// bf16 MFMA GEMMs for gfx950 (MI355X).
+// bf16 MFMA GEMMs for gfx950 (MI355X): the C-ABI entry points and the 128x128 kernels.
 //
 //  gemm_nt : C[M,N]  = A[M,K] . B[N,K]^T  (+ fused epilogue)   -- every nn.Linear forward and dgrad
 //  gemm_tn : O[N,K] += P[Mt,N]^T . Q[Mt,K]                      -- every weight gradient
 //
-// Both: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 MFMA
-// 16x16x32 tiles), reduction step 64, operands streamed global->LDS with 16-byte LDS-DMA
-// (global_load_lds_dwordx4) into a 2-stage ring, XOR-swizzled on the SOURCE address so the LDS image
-// stays lane-linear while fragment reads are bank-conflict free.
+// kzv_gemm_nt / kzv_gemm_tn first offer the shape to the 256x256 eight-phase kernels (gemm_nt256p.hip, gemm_nt256.hip,
+// gemm_tn256.hip: every large GEMM of a ViT layer); what they decline -- the decoder's small GEMMs, K < 128, odd shapes --
+// runs on the kernels in this file: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4
+// MFMA 16x16x32 tiles), reduction step 64, operands streamed global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4)
+// into a 2-stage ring, XOR-swizzled on the SOURCE address so the LDS image stays lane-linear while fragment reads are
+// bank-conflict free; two workgroups per CU.
 //
 // gemm_nt reads both fragments as 16 contiguous bytes (k is the fast axis of A and of B).
 // gemm_tn reduces over the ROW index of both operands, so its fragments come out of LDS through the
@@ -386,12 +388,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
 }  // namespace
 
-static int kzv_nt_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("KZV_NT_VARIANT"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return kzv_fail(KZV_E_ARG, "gemm_nt: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return kzv_fail(KZV_E_ARG, "gemm_nt: empty shape");
@@ -437,7 +433,6 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     // Measured on MI355X (tools/dev/gemm_bench.py, round 1): 128x128x64 / 2-stage ring / 2 workgroups per CU is the
     // fastest of the variants this template expresses (KB = 32 with 2-4 stages: -5..-15 %; 256x128 tiles at one
     // workgroup per CU: -3 %; a 3-stage ring at one workgroup per CU: -30 %), so only it is instantiated.
-    (void)kzv_nt_variant;
     KZV_NT_VARIANT(2, 2, 2, 64, false)
 #undef KZV_NT_VARIANT
 #undef KZV_NT_CASE
