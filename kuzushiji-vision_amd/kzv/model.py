@@ -252,7 +252,8 @@ class TrOCRModel:
         candidates ranked >= num_beams dropped, hypothesis score = sum log-prob / len**length_penalty, early stopping once
         num_beams hypotheses are finished) -- what the reference asks of ``decoder.generate(num_beams=4,
         early_stopping=True)`` (trocr_model.py:306-316).  Parity with HF's implementation is UNPINNED.
-        The beam bookkeeping (top-k, log-softmax over [B*beams, V]) is host-side torch glue, like HF's own Python."""
+        The beam bookkeeping (top-k, log-softmax over [B*beams, V], hypothesis lists) is torch glue on the device, vectorised
+        over the batch."""
         import torch
         c = self.cfg
         px = self._check_inputs(pixel_values)
@@ -289,59 +290,77 @@ class TrOCRModel:
             self.training = was
             return ids[:, :n]
 
-        beam_scores = torch.zeros(B, nb, device=self.device)
+        # Beam bookkeeping on the device, vectorised over the batch (HF's rules; one host sync per step for the stop test):
+        #   candidates = top 2*nb of [nb beams x V]; an EOS candidate counts as a finished hypothesis iff its rank < nb;
+        #   the first nb non-EOS candidates (rank order) become the new beams (each beam yields at most one EOS candidate,
+        #   so at least nb non-EOS ones exist); every batch element keeps its best nb hypotheses.
+        dev = self.device
+        NEG = -1e30
+        beam_scores = torch.zeros(B, nb, device=dev)
         beam_scores[:, 1:] = -1e9
-        hyps = [[] for _ in range(B)]                  # (score, token list)
-        done = [False] * B
+        hyp_scores = torch.full((B, nb), NEG, device=dev)
+        hyp_ids = torch.full((B, nb, Lh), c.pad_id, dtype=torch.int64, device=dev)
+        hyp_len = torch.zeros(B, nb, dtype=torch.int64, device=dev)
+        hyp_cnt = torch.zeros(B, dtype=torch.int64, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        rank = torch.arange(2 * nb, device=dev).view(1, -1)
+        base = (torch.arange(B, device=dev) * nb).view(-1, 1)
         cur = 1
+
+        def merge(h_s, h_i, h_l, c_s, c_i, c_l):
+            """keep the best nb of the union (existing first, so ties keep the earlier hypothesis like a stable sort)"""
+            sc = torch.cat([h_s, c_s], 1)
+            top, idx = sc.topk(nb, dim=1)
+            allid = torch.cat([h_i, c_i], 1)
+            return top, allid.gather(1, idx.unsqueeze(-1).expand(-1, -1, Lh)), torch.cat([h_l, c_l], 1).gather(1, idx)
+
         for t in range(Lh - 1):
             lp = torch.log_softmax(logits_at(t), dim=-1) + beam_scores.view(-1, 1)
             top_s, top_i = lp.view(B, nb * c.vocab).topk(2 * nb, dim=1)
-            top_s, top_i = top_s.cpu(), top_i.cpu()
-            ids_cpu = ids[:, :cur].cpu()
-            new_rows, new_tok, new_sc = [], [], []
-            for b in range(B):
-                if done[b]:
-                    new_rows += [b * nb] * nb; new_tok += [c.pad_id] * nb; new_sc += [0.0] * nb
-                    continue
-                got = 0
-                for rank in range(2 * nb):
-                    beam, tok, sc = int(top_i[b, rank]) // c.vocab, int(top_i[b, rank]) % c.vocab, float(top_s[b, rank])
-                    if tok == c.eos_id:
-                        if rank >= nb:
-                            continue
-                        seq = ids_cpu[b * nb + beam].tolist()
-                        hyps[b].append((sc / (len(seq) ** length_penalty), seq))
-                    else:
-                        new_rows.append(b * nb + beam); new_tok.append(tok); new_sc.append(sc)
-                        got += 1
-                    if got == nb:
-                        break
-                if len(hyps[b]) >= nb:
-                    hyps[b] = sorted(hyps[b], key=lambda h: -h[0])[:nb]          # BeamHypotheses keeps the best num_beams
-                    if early_stopping:
-                        done[b] = True
-                    else:   # HF heuristic: stop when even the best open beam cannot beat the worst kept hypothesis
-                        done[b] = hyps[b][-1][0] >= float(top_s[b, 0]) / ((cur + 1) ** length_penalty)
-            rows = torch.tensor(new_rows, device=self.device)
-            ids = ids[rows].contiguous()
-            ids[:, cur] = torch.tensor(new_tok, device=self.device)
-            beam_scores = torch.tensor(new_sc, device=self.device).view(B, nb)
+            beam, tok = top_i // c.vocab, top_i % c.vocab
+            is_eos = tok == c.eos_id
+            active = ~done
+            # finished hypotheses of this step: EOS candidates of rank < nb (sequence = the beam's ids so far, length cur)
+            take = is_eos[:, :nb] & active.view(-1, 1)
+            c_s = torch.where(take, top_s[:, :nb] / (cur ** length_penalty), torch.full_like(top_s[:, :nb], NEG))
+            c_i = ids.view(B, nb, Lh).gather(1, beam[:, :nb].unsqueeze(-1).expand(-1, -1, Lh))
+            c_l = torch.full((B, nb), cur, dtype=torch.int64, device=dev)
+            hyp_scores, hyp_ids, hyp_len = merge(hyp_scores, hyp_ids, hyp_len, c_s, c_i, c_l)
+            hyp_cnt = torch.clamp(hyp_cnt + take.sum(1), max=nb)
+            # new beams: the first nb non-EOS candidates in rank order
+            non = ~is_eos
+            pos = non.cumsum(1) - 1
+            sel = non & (pos < nb)
+            order = torch.where(sel, pos, torch.full_like(pos, 2 * nb)).argsort(1)[:, :nb]      # candidate index of new beam k
+            nb_beam, nb_tok, nb_sc = beam.gather(1, order), tok.gather(1, order), top_s.gather(1, order)
+            # finished batch elements keep their rows and write padding (scores irrelevant from here on)
+            full = hyp_cnt >= nb
+            if early_stopping:
+                newly = full
+            else:   # HF heuristic: stop when even the best open beam cannot beat the worst kept hypothesis
+                newly = full & (hyp_scores[:, -1] >= top_s[:, 0] / ((cur + 1) ** length_penalty))
+            keep = done.view(-1, 1)
+            rows = torch.where(keep, base.expand(-1, nb), base + nb_beam)
+            nb_tok = torch.where(keep, torch.full_like(nb_tok, c.pad_id), nb_tok)
+            nb_sc = torch.where(keep, torch.zeros_like(nb_sc), nb_sc)
+            done = done | (active & newly)
+            ids = ids[rows.reshape(-1)].contiguous()
+            ids[:, cur] = nb_tok.reshape(-1)
+            beam_scores = nb_sc
             cur += 1
-            if all(done):
+            if bool(done.all()):
                 break
-        ids_cpu = ids[:, :cur].cpu()
-        out = torch.full((B, min(cur + 1, Lh)), c.pad_id, dtype=torch.int64)
-        for b in range(B):
-            if not done[b]:
-                for k in range(nb):
-                    seq = ids_cpu[b * nb + k].tolist()
-                    hyps[b].append((float(beam_scores[b, k]) / (len(seq) ** length_penalty), seq))
-            best = max(hyps[b], key=lambda h: h[0])[1]
-            best = best + [c.eos_id] if len(best) < out.shape[1] else best[:out.shape[1]]
-            out[b, :len(best)] = torch.tensor(best)
+        # open beams of unfinished batch elements compete as hypotheses of their current length
+        c_s = torch.where(done.view(-1, 1), torch.full_like(beam_scores, NEG), beam_scores / (cur ** length_penalty))
+        c_l = torch.full((B, nb), cur, dtype=torch.int64, device=dev)
+        hyp_scores, hyp_ids, hyp_len = merge(hyp_scores, hyp_ids, hyp_len, c_s, ids.view(B, nb, Lh), c_l)
+        width = min(cur + 1, Lh)
+        best_ids, best_len = hyp_ids[:, 0, :width].clone(), hyp_len[:, 0]
+        col = torch.arange(width, device=dev).view(1, -1)
+        out = torch.where(col < best_len.view(-1, 1), best_ids, torch.full_like(best_ids, c.pad_id))
+        out = torch.where((col == best_len.view(-1, 1)) & (best_len.view(-1, 1) < width), torch.full_like(out, c.eos_id), out)
         self.training = was
-        return out.to(self.device)
+        return out
 
     # ------------------------------------------------------------------ Lightning-shaped steps (:323-398)
     def training_step(self, batch, batch_idx):
