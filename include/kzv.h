@@ -183,6 +183,29 @@ uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
  * when world_size > 1. */
 int kzv_set_cu_reserve(int n);
 
+/* ------------------------------------------------------------------ N2: input pipeline on the device
+ * Replaces ResizeWithPadding + ToTensor + Normalize(0.5, 0.5) (src/data/trocr_dataset.py:24-53, 97-104) for a batch of
+ * decoded uint8 RGB crops of different sizes: Pillow's two-pass LANCZOS resample (bit-exact: fixed-point coefficients,
+ * uint8 intermediate), centred paste on a white canvas, [-1, 1] fp32 CHW output.
+ *
+ * kzv_lanczos_coeffs (HOST, no GPU needed; also usable from DataLoader workers): Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc for resampling `in_size` samples to `out_size`: bounds[out][2] = (first input index, count),
+ * kk[out][ksize] = 22-bit fixed-point weights; returns ksize through *ksize (call with kk == NULL to query it).
+ * kzv_preprocess_lines (device pointers): rgb = the crops packed back to back (HWC, 3 bytes per pixel), desc[i] locates
+ * crop i, its geometry and its coefficient tables inside `coef` (int32 offsets); tmp = scratch for the horizontal pass
+ * (desc[i].tmp_off, in_h * new_w * 3 bytes per crop); max_tmp_pixels = max over crops of in_h * new_w (sizes the launch);
+ * lut256 = the 256 possible output values; out = [n, 3, target_h, target_w] fp32. */
+typedef struct {
+    int64_t src_off;            /* byte offset of the crop in `rgb` */
+    int64_t tmp_off;            /* byte offset of its scratch in `tmp` */
+    int64_t hb_off, hk_off;     /* int32 offsets in `coef`: horizontal bounds [new_w][2], weights [new_w][hk_size] */
+    int64_t vb_off, vk_off;     /* vertical bounds [new_h][2], weights [new_h][vk_size] */
+    int32_t in_h, in_w, new_h, new_w, paste_x, paste_y, hk_size, vk_size;
+} kzv_line_desc;
+int kzv_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int* ksize);
+int kzv_preprocess_lines(const uint8_t* rgb, const kzv_line_desc* desc, const int32_t* coef, int n, int target_h, int target_w,
+                         int64_t max_tmp_pixels, const float* lut256, uint8_t* tmp, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ constexpr int HT_BYTES = 128 * 128;        // half-tile: 128 rows x 64 bf16
 constexpr int BUF_BYTES = 4 * HT_BYTES;    // A-h0, A-h1, B-h0, B-h1
 constexpr int RING_BYTES = 2 * BUF_BYTES;  // 128 KiB
 constexpr int LDS_BYTES = RING_BYTES + 8 * 4096;   // + one 4-KiB drain patch per wave = 160 KiB
-constexpr int KA0 = 0, KA1 = 1, KB0 = 2, KB1 = 3;
+constexpr int KA0 = 0, KB0 = 2;             // half-tile slots of a ring buffer: A-h0, A-h1, B-h0, B-h1
 
 __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
 
     TileSrc s1, s2;                    // s1 feeds A-h1/B-h1 of stream K-tile u+1, s2 feeds A-h0/B-h0 of K-tile u+2
     constexpr int D = drain_ops<EPI>();
-    constexpr int W8 = cmin(63, 8 + D), W4 = cmin(63, 4 + D);
+    constexpr int W8 = cmin(63, 8 + D);
 
     // One K-tile of the stream = four phases (gemm_nt256.hip).  e1 / e2: stream K-tiles u+1 / u+2 exist.
     // `after_drain`: this is the first K-tile after a credited drain (waits widened by D).

@@ -56,6 +56,12 @@ EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)
 
 # every symbol include/kzv.h declares: (restype, argtypes)
 _P = C.c_void_p
+class kzv_line_desc(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("tmp_off", C.c_int64), ("hb_off", C.c_int64), ("hk_off", C.c_int64),
+                ("vb_off", C.c_int64), ("vk_off", C.c_int64), ("in_h", C.c_int32), ("in_w", C.c_int32), ("new_h", C.c_int32),
+                ("new_w", C.c_int32), ("paste_x", C.c_int32), ("paste_y", C.c_int32), ("hk_size", C.c_int32), ("vk_size", C.c_int32)]
+
+
 SYMBOLS = {
     "kzv_last_error": (C.c_char_p, []),
     "kzv_version": (C.c_int, []),
@@ -89,6 +95,9 @@ SYMBOLS = {
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "kzv_prof_select": (C.c_int, [C.c_uint]),
     "kzv_set_cu_reserve": (C.c_int, [C.c_int]),
+    "kzv_lanczos_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "kzv_preprocess_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "kzv_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
@@ -103,6 +112,9 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise KzvError(f"{LIB_PATH} not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch first: it ships its own libamdhip64; loaded after libkzv.so the process would hold two HIP runtimes (torch's
+    # tensors in one, libkzv's launches in the other -> "no ROCm-capable device is detected" at the first launch)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol

@@ -127,12 +127,13 @@ class LineCsvDataset:
     "image_path"}; deterministic 42-seeded shuffle, then train/val/test slices; unreadable images become zeros."""
 
     def __init__(self, csv_path, image_root, tokenizer, image_size=(1024, 64), max_length=128, split="train",
-                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1):
+                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, device_preprocess=False):
         import ast
         import pandas as pd
         if abs(train_ratio + val_ratio + test_ratio - 1.0) >= 1e-6:
             raise AssertionError("Ratios must sum to 1.0")
         self.image_root, self.image_size, self.max_length, self.tokenizer = image_root, tuple(image_size), max_length, tokenizer
+        self.device_preprocess = bool(device_preprocess)
         df = pd.read_csv(csv_path).dropna()
         df["unicode_ids"] = df["unicode_ids"].apply(ast.literal_eval)
         df["text"] = df["unicode_ids"].apply(self._ids_to_text)
@@ -169,24 +170,75 @@ class LineCsvDataset:
         row = self.data.iloc[idx]
         rel = row["column_image"]
         path = rel if rel.startswith(self.image_root) else os.path.join(self.image_root, os.path.basename(rel))
+        enc = self.tokenizer(row["text"], max_length=self.max_length, padding="max_length", truncation=True,
+                             return_tensors="pt")
+        item = {"labels": enc["input_ids"].squeeze(0), "text": row["text"], "image_path": path}
+        if self.device_preprocess:
+            # N2: hand the decoded uint8 crop (and its resampling plan) to kzv.preprocess.DevicePreprocessor; an unreadable
+            # image becomes None -> an all-zero tensor after the device pass, like the reference's fallback
+            from .preprocess import plan_line
+            try:
+                u8 = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+                item["image_u8"], item["plan"] = u8, plan_line(u8.shape[0], u8.shape[1], self.image_size[0], self.image_size[1])
+            except Exception:
+                item["image_u8"], item["plan"] = None, None
+            return item
         try:
             px = image_to_tensor(resize_with_padding(Image.open(path).convert("RGB"), self.image_size))
         except Exception:
             px = torch.zeros(3, self.image_size[0], self.image_size[1])
-        enc = self.tokenizer(row["text"], max_length=self.max_length, padding="max_length", truncation=True,
-                             return_tensors="pt")
-        return {"pixel_values": px, "labels": enc["input_ids"].squeeze(0), "text": row["text"], "image_path": path}
+        item["pixel_values"] = px
+        return item
+
+
+def collate_raw(items):
+    """collate for device_preprocess datasets: crops stay a list (ragged sizes); see device_batch"""
+    import torch
+    return {"image_u8": [i["image_u8"] for i in items], "plan": [i["plan"] for i in items],
+            "labels": torch.stack([i["labels"] for i in items]),
+            "text": [i["text"] for i in items], "image_path": [i["image_path"] for i in items]}
+
+
+def device_batch(batch, preprocessor):
+    """raw batch -> the reference's batch dict with pixel_values produced on the GPU (kzv.preprocess.DevicePreprocessor)"""
+    ok = [k for k, im in enumerate(batch["image_u8"]) if im is not None]
+    import torch
+    n = len(batch["image_u8"])
+    px = torch.zeros(n, 3, preprocessor.target_h, preprocessor.target_w, device=preprocessor.device)
+    if ok:
+        got = preprocessor([batch["image_u8"][k] for k in ok], plans=[batch["plan"][k] for k in ok])
+        px[torch.tensor(ok, device=px.device)] = got
+    out = {k: v for k, v in batch.items() if k not in ("image_u8", "plan")}
+    out["pixel_values"] = px
+    return out
 
 
 def collate(items):
     import torch
+    if "image_u8" in items[0]:
+        return collate_raw(items)
     return {"pixel_values": torch.stack([i["pixel_values"] for i in items]),
             "labels": torch.stack([i["labels"] for i in items]),
             "text": [i["text"] for i in items], "image_path": [i["image_path"] for i in items]}
 
 
-def make_loader(dataset, batch_size, shuffle, seed=42, rank=0, world=1, drop_last=False):
-    """DataLoader with a DistributedSampler-style shard (every rank sees len/world samples of the same permutation)."""
+class DeviceBatchLoader:
+    """Wraps a loader of raw batches (device_preprocess datasets): every batch leaves with pixel_values made on the GPU."""
+
+    def __init__(self, loader, preprocessor):
+        self.loader, self.preprocessor = loader, preprocessor
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for b in self.loader:
+            yield device_batch(b, self.preprocessor)
+
+
+def make_loader(dataset, batch_size, shuffle, seed=42, rank=0, world=1, drop_last=False, num_workers=0, preprocessor=None):
+    """DataLoader with a DistributedSampler-style shard (every rank sees len/world samples of the same permutation).
+    `preprocessor` (kzv.preprocess.DevicePreprocessor): for datasets built with device_preprocess=True."""
     import torch
     from torch.utils.data import DataLoader, Subset
     idx = list(range(len(dataset)))
@@ -196,4 +248,6 @@ def make_loader(dataset, batch_size, shuffle, seed=42, rank=0, world=1, drop_las
     if world > 1:
         per = (len(idx) + world - 1) // world
         idx = (idx + idx[: per * world - len(idx)])[rank::world]
-    return DataLoader(Subset(dataset, idx), batch_size=batch_size, shuffle=False, collate_fn=collate, drop_last=drop_last)
+    loader = DataLoader(Subset(dataset, idx), batch_size=batch_size, shuffle=False, collate_fn=collate, drop_last=drop_last,
+                        num_workers=num_workers)
+    return DeviceBatchLoader(loader, preprocessor) if preprocessor is not None else loader

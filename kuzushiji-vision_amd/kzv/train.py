@@ -53,6 +53,8 @@ def parse_args(argv=None):
     p.add_argument("--accelerator", type=str, default="gpu")
     p.add_argument("--precision", type=str, default="bf16-mixed", choices=["16-mixed", "32", "bf16-mixed"])
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--device_preprocess", action="store_true",
+                   help="resize / pad / normalise the decoded crops on the GPU (kzv.preprocess; byte-exact with the PIL transform)")
     p.add_argument("--ema_decay", type=float, default=0.0, help="> 0 attaches kzv.ema.EMACallback (reference: decay 0.9999)")
     return p.parse_args(argv)
 
@@ -102,9 +104,14 @@ def main(argv=None):
     else:
         kw = dict(csv_path=args.csv_path, image_root=args.image_root, tokenizer=model.tokenizer, image_size=tuple(args.image_size),
                   max_length=args.max_length, train_ratio=args.train_ratio, val_ratio=args.val_ratio, test_ratio=args.test_ratio)
+        kw["device_preprocess"] = args.device_preprocess
         train_ds, val_ds = LineCsvDataset(split="train", **kw), LineCsvDataset(split="val", **kw)
-    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, drop_last=True)
-    val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world)
+    pre = None
+    if args.device_preprocess and not args.synthetic:
+        from .preprocess import DevicePreprocessor
+        pre = DevicePreprocessor(tuple(args.image_size), device=f"cuda:{local}")
+    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, drop_last=True, preprocessor=pre)
+    val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world, preprocessor=pre)
     if rank == 0:
         print(f"Train samples: {len(train_ds)}\nVal samples: {len(val_ds)}\nParameters: {model.num_parameters():,}")
     cbs = []
