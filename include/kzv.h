@@ -191,14 +191,15 @@ int kzv_set_cu_reserve(int n);
  * kzv_lanczos_coeffs (HOST, no GPU needed; also usable from DataLoader workers): Pillow's precompute_coeffs +
  * normalize_coeffs_8bpc for resampling `in_size` samples to `out_size`: bounds[out][2] = (first input index, count),
  * kk[out][ksize] = 22-bit fixed-point weights; returns ksize through *ksize (call with kk == NULL to query it).
- * kzv_preprocess_lines (device pointers): rgb = the crops packed back to back (HWC, 3 bytes per pixel), desc[i] locates
+ * kzv_preprocess_lines (device pointers; `rgb` and `tmp` need 4 bytes of slack after their last byte: pixels are fetched
+ * as unaligned 32-bit words): rgb = the crops packed back to back (HWC, 3 bytes per pixel), desc[i] locates
  * crop i, its geometry and its coefficient tables inside `coef` (int32 offsets); tmp = scratch for the horizontal pass
  * (desc[i].tmp_off, in_h * new_w * 3 bytes per crop); max_tmp_pixels = max over crops of in_h * new_w (sizes the launch);
  * lut256 = the 256 possible output values; out = [n, 3, target_h, target_w] fp32. */
 typedef struct {
     int64_t src_off;            /* byte offset of the crop in `rgb` */
     int64_t tmp_off;            /* byte offset of its scratch in `tmp` */
-    int64_t hb_off, hk_off;     /* int32 offsets in `coef`: horizontal bounds [new_w][2], weights [new_w][hk_size] */
+    int64_t hb_off, hk_off;     /* int32 offsets in `coef`: horizontal bounds [new_w][2], weights TRANSPOSED [hk_size][new_w] */
     int64_t vb_off, vk_off;     /* vertical bounds [new_h][2], weights [new_h][vk_size] */
     int32_t in_h, in_w, new_h, new_w, paste_x, paste_y, hk_size, vk_size;
 } kzv_line_desc;

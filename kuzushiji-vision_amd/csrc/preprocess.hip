@@ -19,6 +19,12 @@ namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
 
+// one unaligned 32-bit load fetches the three channel bytes of a pixel (+1 byte of its neighbour): the kernels are bound
+// by address processing of byte gathers, not by bytes, so this is 3x fewer memory instructions.  The packed crop buffer
+// and the intermediate carry 4 bytes of slack at the end for the last pixel.
+typedef unsigned u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ unsigned load_rgbx(const uint8_t* px) { return *(const u32_unaligned*)px; }
+
 __device__ __forceinline__ int clip8(int v) { v >>= PRECISION_BITS; return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
 // pass 1: tmp[y][xo][c] for y < in_h, xo < new_w (a plain copy when the width is unchanged: Pillow skips the pass)
@@ -32,12 +38,13 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
     uint8_t* o = tmp + d.tmp_off + ((int64_t)y * d.new_w + xo) * 3;
     if (d.new_w == d.in_w) { o[0] = row[xo * 3]; o[1] = row[xo * 3 + 1]; o[2] = row[xo * 3 + 2]; return; }
     const int xmin = coef[d.hb_off + 2 * xo], cnt = coef[d.hb_off + 2 * xo + 1];
-    const int32_t* k = coef + d.hk_off + (int64_t)xo * d.hk_size;
+    const int32_t* k = coef + d.hk_off + xo;            // horizontal weights are stored TRANSPOSED [hk_size][new_w]: coalesced over xo
     int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll 4
     for (int i = 0; i < cnt; ++i) {
-        const int w = k[i];
-        const uint8_t* px = row + (xmin + i) * 3;
-        s0 += px[0] * w; s1 += px[1] * w; s2 += px[2] * w;
+        const int w = k[(int64_t)i * d.new_w];
+        const unsigned v = load_rgbx(row + (xmin + i) * 3);
+        s0 += (int)(v & 0xff) * w; s1 += (int)((v >> 8) & 0xff) * w; s2 += (int)((v >> 16) & 0xff) * w;
     }
     o[0] = (uint8_t)clip8(s0); o[1] = (uint8_t)clip8(s1); o[2] = (uint8_t)clip8(s2);
 }
@@ -62,10 +69,11 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const kzv_line_desc* __
             const int ymin = coef[d.vb_off + 2 * yo], cnt = coef[d.vb_off + 2 * yo + 1];
             const int32_t* k = coef + d.vk_off + (int64_t)yo * d.vk_size;
             int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll 4
             for (int i = 0; i < cnt; ++i) {
                 const int w = k[i];
-                const uint8_t* px = col + (ymin + i) * rs;
-                s0 += px[0] * w; s1 += px[1] * w; s2 += px[2] * w;
+                const unsigned v = load_rgbx(col + (ymin + i) * rs);
+                s0 += (int)(v & 0xff) * w; s1 += (int)((v >> 8) & 0xff) * w; s2 += (int)((v >> 16) & 0xff) * w;
             }
             v0 = clip8(s0); v1 = clip8(s1); v2 = clip8(s2);
         }

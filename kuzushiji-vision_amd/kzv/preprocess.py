@@ -39,12 +39,21 @@ def lanczos_coeffs(in_size: int, out_size: int):
     return bounds, kk
 
 
+@functools.lru_cache(maxsize=4096)
+def _lanczos_coeffs_t(in_size: int, out_size: int):
+    """horizontal-pass form: weights transposed to [ksize, out] (adjacent output pixels read adjacent words on the GPU)"""
+    b, k = lanczos_coeffs(in_size, out_size)
+    kt = np.ascontiguousarray(k.T)
+    kt.setflags(write=False)
+    return b, kt
+
+
 def plan_line(h: int, w: int, target_h: int, target_w: int) -> dict:
     """Everything `DevicePreprocessor` needs for one crop besides its pixels."""
     new_w, new_h, px, py = target_geometry(w, h, target_h, target_w)
     plan = {"in_h": h, "in_w": w, "new_h": new_h, "new_w": new_w, "paste_x": px, "paste_y": py, "h": None, "v": None}
     if new_w != w:
-        plan["h"] = lanczos_coeffs(w, new_w)
+        plan["h"] = _lanczos_coeffs_t(w, new_w)
     if new_h != h:
         plan["v"] = lanczos_coeffs(h, new_h)
     return plan
@@ -86,11 +95,11 @@ class DevicePreprocessor:
                 b, k = p[key]
                 setattr(d, boff, coef_len); coef_parts.append(b.ravel()); coef_len += b.size
                 setattr(d, koff, coef_len); coef_parts.append(k.ravel()); coef_len += k.size
-                setattr(d, ksz, k.shape[1])
+                setattr(d, ksz, k.shape[0] if key == "h" else k.shape[1])
             src_off += im.shape[0] * im.shape[1] * 3
             tmp_off += p["in_h"] * p["new_w"] * 3
             max_tmp = max(max_tmp, p["in_h"] * p["new_w"])
-        rgb = np.empty(src_off, np.uint8)
+        rgb = np.zeros(src_off + 4, np.uint8)             # + slack: the kernels fetch a pixel as one unaligned 32-bit word
         o = 0
         for im in images:
             sz = im.size
@@ -99,7 +108,7 @@ class DevicePreprocessor:
         d_rgb = torch.from_numpy(rgb).to(self.device, non_blocking=True)
         d_coef = torch.from_numpy(coef).to(self.device, non_blocking=True)
         d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(self.device, non_blocking=True)
-        d_tmp = torch.empty(max(1, tmp_off), dtype=torch.uint8, device=self.device)
+        d_tmp = torch.empty(tmp_off + 4, dtype=torch.uint8, device=self.device)
         if out is None:
             out = torch.empty(n, 3, self.target_h, self.target_w, dtype=torch.float32, device=self.device)
         L.check(L.load().kzv_preprocess_lines(d_rgb.data_ptr(), d_desc.data_ptr(), d_coef.data_ptr(), n, self.target_h, self.target_w,
