@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling: global = batch * gpus)")
     ap.add_argument("--dec-layers", type=int, default=6, help="6 = BASELINE.json configs[1]; 12 = reference decoder")
+    ap.add_argument("--encoder", choices=["vit_b", "vit_l"], default="vit_b",
+                    help="vit_b = the benchmark (configs[1]/[2]); vit_l = configs[3]'s ViT-L/16 encoder (a side measurement)")
     ap.add_argument("--label-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
@@ -101,7 +103,7 @@ def main():
 
     import torch
     from kzv import _lib as L
-    from kzv.config import vit_b_config
+    from kzv.config import vit_b_config, vit_l_config
     from kzv.data import build_decoder_dir, synthetic_batch
     from kzv.model import TrOCRModel
     from kzv.trainer import Stepper, init_distributed
@@ -111,7 +113,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    cfg = vit_b_config(dec_layers=args.dec_layers)
+    cfg = vit_b_config(dec_layers=args.dec_layers) if args.encoder == "vit_b" else vit_l_config(dec_layers=args.dec_layers)
     lib = L.load()
 
     with tempfile.TemporaryDirectory() as tmp:
@@ -188,9 +190,9 @@ def main():
             "metric": "line-images/sec (train)", "value": imgs / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"TrOCR train step: ViT-B/16 (12L/768/12h/3072) on 64x640 crops (S_e=161) + RoBERTa "
+            "config": {"workload": f"TrOCR train step: {'ViT-B/16 (12L/768/12h/3072)' if args.encoder == 'vit_b' else 'ViT-L/16 (24L/1024/16h/4096)'} on 64x640 crops (S_e=161) + RoBERTa "
                                    f"decoder {args.dec_layers}L/256/4h/768, V=4300 one-char vocab, labels [B,{args.label_len}], "
-                                   f"dropout 0.1, clip 1.0, RAdamScheduleFree; BASELINE.json configs[{1 if world == 1 else 2}]",
+                                   f"dropout 0.1, clip 1.0, RAdamScheduleFree; BASELINE.json configs[{(1 if world == 1 else 2) if args.encoder == 'vit_b' else 3}]",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "decoder_positions": DECPOS,
                        "final_loss": final_loss},

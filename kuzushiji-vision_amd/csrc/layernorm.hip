@@ -352,7 +352,7 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     const size_t lds = 8 * H * sizeof(float);
     p.partial = ln_partials();
     if (!p.partial) return kzv_fail(KZV_E_HIP, "layernorm_bwd: partial-sum buffer unavailable");
-    const bool fast = H == ncl * 256 && (ncl == 1 || ncl == 3);
+    const bool fast = H == ncl * 256 && ncl <= 4;
 #define KZV_LN_FAST(NC)                                                                                       \
     do {                                                                                                      \
         if (dy_is_f32) { if (accumulate_dx) hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, true, true>), grid, dim3(256), lds, s, p);   \
@@ -361,7 +361,9 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
                else hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, false, false>), grid, dim3(256), lds, s, p); }                       \
     } while (0)
     if (fast && ncl == 1) KZV_LN_FAST(1);
+    else if (fast && ncl == 2) KZV_LN_FAST(2);
     else if (fast && ncl == 3) KZV_LN_FAST(3);
+    else if (fast && ncl == 4) KZV_LN_FAST(4);
     else if (ncl <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), lds, s, p);
     else if (ncl == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), lds, s, p);
     else if (ncl == 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, dim3(256), lds, s, p);

@@ -163,6 +163,13 @@ def vit_b_config(dec_layers: int = 12) -> ModelConfig:
                        dec_hidden=256, dec_layers=dec_layers, dec_heads=4, dec_ffn=768, vocab=4300, max_pos=128)
 
 
+def vit_l_config(enc_layers: int = 24, dec_layers: int = 12) -> ModelConfig:
+    """configs[3]: TrOCR-large geometry -- ViT-L/16 encoder (1024 / 16 heads / FFN 4096) on 64x640 crops + the 12-layer
+    reference decoder; `enc_layers` lets tests keep the oracle fast."""
+    return ModelConfig(image_h=64, image_w=640, enc_hidden=1024, enc_layers=enc_layers, enc_heads=16, enc_ffn=4096,
+                       dec_hidden=256, dec_layers=dec_layers, dec_heads=4, dec_ffn=768, vocab=4300, max_pos=128)
+
+
 def small_config() -> ModelConfig:
     """configs[0]: 'TrOCR-small' plumbing case (6 L / 384 / 6 heads encoder + reference decoder)."""
     return ModelConfig(image_h=64, image_w=640, enc_hidden=384, enc_layers=6, enc_heads=6, enc_ffn=1536,

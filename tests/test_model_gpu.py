@@ -270,6 +270,28 @@ def test_edge_geometries_match_oracle(tmp_path, B, L, kw):
         assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, k
 
 
+def test_vit_large_geometry_matches_oracle(tmp_path):
+    """BASELINE.json configs[3] as a parity case: ViT-L/16 widths (1024 hidden, 16 heads, FFN 4096; 2 of the 24 layers so
+    that the CPU oracle finishes in seconds) + a 2-layer reference decoder, B = 3, against the oracle on fresh inputs."""
+    from kzv.config import vit_l_config
+    cfg = _no_dropout(vit_l_config(enc_layers=2, dec_layers=2))
+    m = _make(cfg, tmp_path, 5)
+    px, lab = synthetic_batch(cfg, 3, 24, seed=11, min_chars=3, max_chars=20)
+    m.train()
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    m.backward()
+    torch.cuda.synchronize()
+    r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 5)), px, lab)
+    assert np.abs(out["logits"].cpu().numpy() - r["logits"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - r["loss"]) < 5e-3
+    g = m.grad_dict()
+    for k, v in r["grads"].items():
+        if v is None or k.endswith("key.bias"):
+            continue
+        got = g[k].cpu().numpy().reshape(v.shape)
+        assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, k
+
+
 def test_zero_layer_models_are_rejected(tmp_path):
     import dataclasses
     from kzv._lib import KzvError
