@@ -85,6 +85,18 @@ int kzv_set_active_length(kzv_model* m, int t_active);
  * pos only depends on ids[:, :pos+1].  Invalidates the saved activations (no backward afterwards). */
 int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos, float* d_logits, void* stream);
 
+/* KV-cached generation step (what `decoder.generate(use_cache=True)` does per token, trocr_model.py:306-316): feeds ONE
+ * token per sequence -- d_tokens [B] at decoder index t, with RoBERTa position ids d_posids [B] (t + 1 + pad_id for a live
+ * sequence, pad_id for padding) -- through the decoder against the self-attention keys / values cached by steps 0..t-1
+ * (this step's are appended) and the cross-attention K/V of the last kzv_forward_loss; d_valid [B, ld_valid] marks the
+ * usable self-attention keys (key j usable iff token j is not padding; column t must already be set).  Writes logits
+ * [B, V] for the next token.  Steps must be issued in order t = 0, 1, ...; the cache is sized [B, L-1] at the first call.
+ * kzv_decode_reorder re-orders the cached rows after a beam step: row b continues from former row d_rows[b] (first `len`
+ * key positions). */
+int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, int t, const uint8_t* d_valid, int64_t ld_valid,
+                    float* d_logits, void* stream);
+int kzv_decode_reorder(kzv_model* m, const int64_t* d_rows, int len, void* stream);
+
 /* loss.backward() for the step above: fills the bound fp32 grad buffer (which must be zero on entry;
  * kzv_zero_grads does that).  Backward is split in `kzv_backward_segments()` segments so the host can
  * launch an RCCL all-reduce for a segment's finished gradients while later segments still run

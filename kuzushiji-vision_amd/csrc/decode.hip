@@ -1,0 +1,100 @@
+// N1: KV-cached decoder step: one new token per sequence attends over cached keys / values.
+//
+// Replaces, for generation only, the per-step work of HF RobertaSelfAttention / RobertaCrossAttention with `use_cache=True`
+// (modeling_roberta.py:186-326) as driven by `decoder.generate` (src/models/trocr_model.py:306-316).  One wave per
+// (sequence, head): every lane scores up to 3 keys (<= 192) against the 64-dim query in fp32, softmax across the wave,
+// then lane d accumulates output dimension d over the keys (128-B coalesced V rows).  The self-attention variant also
+// appends this step's key and value to the cache.  Work per step is tiny (B*heads waves); the step is launch-bound.
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "kzv_kernels.h"
+
+namespace {
+
+struct DecAttnP {
+    const bf16_t* q; int64_t ldq;                 // [B, ldq], head h at column h*64
+    const bf16_t* knew; const bf16_t* vnew; int64_t ldnew;   // this step's key/value rows [B, ldnew] (self-attention) or null
+    bf16_t* K; bf16_t* V; int64_t kb, kj;         // key j of sequence b: K + b*kb + j*kj + h*64 (same strides for V)
+    const unsigned char* valid; int64_t ldvalid;  // [B, ldvalid]: key j usable (null: all)
+    bf16_t* out; int64_t ldo;
+    int nkeys, append_at, heads;                  // append_at >= 0: write knew/vnew at key index append_at first
+    float scale;
+};
+
+__global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
+    __shared__ float prob[192];
+    __shared__ float qs[64];
+    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, lane = threadIdx.x;
+    bf16_t* Kb = p.K + (int64_t)b * p.kb + h * 64;
+    bf16_t* Vb = p.V + (int64_t)b * p.kb + h * 64;
+    if (p.append_at >= 0) {                       // lane d copies dimension d of the new key and value into the cache
+        Kb[(int64_t)p.append_at * p.kj + lane] = p.knew[(int64_t)b * p.ldnew + h * 64 + lane];
+        Vb[(int64_t)p.append_at * p.kj + lane] = p.vnew[(int64_t)b * p.ldnew + h * 64 + lane];
+    }
+    qs[lane] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + lane]) * p.scale;
+    __syncthreads();                              // cache row + query visible to the whole wave
+    float sc[3];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int j = lane + 64 * u;
+        sc[u] = -INFINITY;
+        if (j < p.nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) {
+            const bf16x8* kr = (const bf16x8*)(Kb + (int64_t)j * p.kj);
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bf16x8 kv = kr[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qs[c * 8 + e] * bf2f((bf16_t)kv[e]);
+            }
+            sc[u] = a;
+        }
+        mx = fmaxf(mx, sc[u]);
+    }
+    mx = wave_max(mx);
+    const bool dead = mx == -INFINITY;            // no usable key (a finished, all-pad row): output zeros
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; }
+    sum = wave_sum(sum);
+    const float inv = dead ? 0.f : 1.f / sum;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) if (lane + 64 * u < 192) prob[lane + 64 * u] = sc[u] * inv;
+    __syncthreads();
+    float o = 0.f;
+    for (int j = 0; j < p.nkeys; ++j) o += prob[j] * bf2f(Vb[(int64_t)j * p.kj + lane]);
+    p.out[(int64_t)b * p.ldo + h * 64 + lane] = f2bf(o);
+}
+
+// beam re-ordering: dst[l][b][j][:] = src[l][idx[b]][j][:] for j < len (16-byte chunks)
+__global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int64_t* __restrict__ idx,
+                                                         int B, int Tmax, int len, int chunks_per_row, int64_t layer_stride16) {
+    const int64_t per_b = (int64_t)len * chunks_per_row;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)B * per_b) return;
+    const int b = (int)(t / per_b);
+    const int64_t r = t - (int64_t)b * per_b;
+    const int64_t lo = (int64_t)blockIdx.y * layer_stride16;
+    dst[lo + (int64_t)b * Tmax * chunks_per_row + r] = src[lo + idx[b] * (int64_t)Tmax * chunks_per_row + r];
+}
+
+}  // namespace
+
+int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
+                    int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
+                    int append_at, hipStream_t s) {
+    if (nkeys < 1 || nkeys > 192) return kzv_fail(KZV_E_ARG, "attn_decode: 1..192 keys");
+    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f};
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(B * heads), dim3(64), 0, s, p);
+    return kzv_check_launch("attn_decode");
+}
+
+int kzv_kv_reorder(const bf16_t* src, bf16_t* dst, const int64_t* idx, int layers2, int B, int Tmax, int len, int Hd, hipStream_t s) {
+    const int cpr = Hd / 8;                       // 16-byte chunks per cache row
+    const int64_t total = (int64_t)B * len * cpr;
+    hipLaunchKernelGGL(kv_reorder_kernel, dim3((unsigned)((total + 255) / 256), layers2), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, idx,
+                       B, Tmax, len, cpr, (int64_t)B * Tmax * cpr);
+    return kzv_check_launch("kv_reorder");
+}

@@ -72,6 +72,8 @@ struct kzv_model {
     // caller's stream (their tails and epilogues fill each other's idle workgroup slots)
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr; hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pending[4] = {false, false, false, false}; bool use_side = false, join_each_segment = true;
+    // KV cache of the generation path (kzv_decode_step): two copies [2*Ld][B][T][Hd] (beam re-ordering gathers from one into the other)
+    bf16_t* kvc[2] = {nullptr, nullptr}; int kv_cur = 0, kvB = 0, kvT = 0;
     bool side_ok = false;    // mode 2: set only inside the encoder-layer schedule (everything else stays on the caller's stream)
     int side_mode = 0;       // 0 off, 1 free-running wgrads, 2 wgrads only under the HBM-bound kernels (LayerNorm / attention backward)
 };
@@ -569,6 +571,7 @@ extern "C" int kzv_model_destroy(kzv_model* m) {
         if (m->side) (void)hipStreamDestroy(m->side);
         if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
         for (int i = 0; i < 4; ++i) if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
+        for (int i = 0; i < 2; ++i) if (m->kvc[i]) (void)hipFree(m->kvc[i]);
     }
     delete m;
     return KZV_OK;
@@ -668,6 +671,69 @@ extern "C" int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos,
     m->train = false;
     m->have_fwd = false;     // decoder activations are overwritten: no backward after this
     return forward(m, nullptr, d_labels, nullptr, d_logits, (hipStream_t)stream, false, pos);
+}
+
+// ---- KV-cached generation step (N1) -------------------------------------------------------------------------------
+static int ensure_kv_cache(kzv_model* m) {
+    if (m->kvc[0] && m->kvB == m->B && m->kvT == m->T) return KZV_OK;
+    for (int i = 0; i < 2; ++i) { if (m->kvc[i]) (void)hipFree(m->kvc[i]); m->kvc[i] = nullptr; }
+    const size_t bytes = (size_t)2 * m->Ld * m->B * m->T * m->Hd * sizeof(bf16_t);
+    for (int i = 0; i < 2; ++i)
+        if (hipMalloc((void**)&m->kvc[i], bytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step: KV cache allocation (%zu bytes)", bytes);
+    m->kvB = m->B; m->kvT = m->T; m->kv_cur = 0;
+    return KZV_OK;
+}
+
+extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const unsigned char* d_valid,
+                               int64_t ld_valid, float* d_logits, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_step: model not bound");
+    if (!m->have_enc) return kzv_fail(KZV_E_STATE, "decode_step: call kzv_forward_loss on the images first");
+    if (!d_tokens || !d_posids || !d_valid || !d_logits || t < 0 || t >= m->T) return kzv_fail(KZV_E_ARG, "decode_step: null operand or step outside 0..T-1");
+    KZV_TRY(ensure_kv_cache(m));
+    hipStream_t s = (hipStream_t)stream;
+    const kzv_config& c = m->c;
+    const int B = m->B, Hd = m->Hd, Fd = m->Fd, T = m->T;
+    float* P = m->P;
+    const float eps = c.ln_eps;
+    const int CK = m->Ld * 2 * Hd;
+    m->train = false; m->have_fwd = false;      // decoder activations are overwritten: no backward after this
+    bf16_t* cache = m->kvc[m->kv_cur];
+    const int64_t plane = (int64_t)B * T * Hd;  // one layer's K (or V) cache
+    // embeddings of the one new token per sequence (HF modeling_roberta.py:75-122; position ids from the caller)
+    KZV_TRY(kzv_embed_gather(d_tokens, 1, d_posids, P + m->word, P + m->dtype, P + m->dpos, m->emb_sum, B, 1, Hd, s));
+    KZV_TRY(kzv_ln_fwd_ex(m->emb_sum, P + m->eln_w, P + m->eln_b, m->xd0h, m->xd0, m->emb_st, B, Hd, eps, 1, 0, 0.f, 0, s));
+    const float* x = m->xd0; const bf16_t* xh = m->xd0h;
+    for (int i = 0; i < m->Ld; ++i) {
+        DecAct& a = m->da[i];
+        const DecLayerP& d = m->dp[i];
+        KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, B, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
+        KZV_TRY(kzv_attn_decode(a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, cache + (int64_t)(2 * i) * plane, cache + (int64_t)(2 * i + 1) * plane,
+                                (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, t + 1, t, s));
+        KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, B, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0, 0.f, 0));
+        KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, B, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
+        KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd,
+                                (int64_t)m->np * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->np, -1, s));
+        KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, B, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0, 0.f, 0));
+        KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, B, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, B, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
+        KZV_TRY(gemm(a.act, Fd, m->w_dfc2[i], false, B, Hd, Fd, Hd, P + d.fc2b, a.s3, Hd, KZV_EPI_RESID, s, a.x2, nullptr, 0, 0.f, 0));
+        KZV_TRY(kzv_ln_fwd_ex(a.s3, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, B, Hd, eps, 1, 0, 0.f, 0, s));
+        x = a.x3; xh = a.x3h;
+    }
+    KZV_TRY(gemm(xh, Hd, m->w_hd, false, B, Hd, Hd, Hd, P + m->hd_b, m->hd_gelu, Hd, KZV_EPI_GELU_F32, s, nullptr, m->hd_pre, Hd));
+    KZV_TRY(kzv_ln_fwd_ex(m->hd_gelu, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, B, Hd, eps, 1, 0, 0.f, 0, s));
+    KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, B, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
+    KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s));
+    return KZV_OK;
+}
+
+extern "C" int kzv_decode_reorder(kzv_model* m, const int64_t* d_rows, int len, void* stream) {
+    if (!m || !m->bound || !m->kvc[0]) return kzv_fail(KZV_E_STATE, "decode_reorder: no KV cache (call kzv_decode_step first)");
+    if (!d_rows || len < 1 || len > m->T) return kzv_fail(KZV_E_ARG, "decode_reorder: rows / length");
+    KZV_TRY(kzv_kv_reorder(m->kvc[m->kv_cur], m->kvc[m->kv_cur ^ 1], d_rows, 2 * m->Ld, m->B, m->T, len, m->Hd, (hipStream_t)stream));
+    m->kv_cur ^= 1;
+    return KZV_OK;
 }
 
 extern "C" int kzv_zero_grads(kzv_model* m, void* stream) {

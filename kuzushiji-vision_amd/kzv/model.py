@@ -243,10 +243,12 @@ class TrOCRModel:
         L.check(lib.kzv_backward(self._h, st), "kzv_backward")
 
     def generate(self, pixel_values, max_length: int = 128, num_beams: int = 1, early_stopping: bool = True,
-                 length_penalty: float = 1.0):
-        """Decode from BOS.  The encoder (and the cross-attention K/V of every decoder layer) runs ONCE; each step is a
-        decoder-only teacher-forced pass (kzv_decode_logits) whose position-t logits only depend on ids[:, :t+1] under
-        the causal mask -- no KV cache, so re-ordering beams is a row gather of the id buffer.
+                 length_penalty: float = 1.0, use_cache: bool = True):
+        """Decode from BOS.  The encoder (and the cross-attention K/V of every decoder layer) runs ONCE.
+        use_cache=True (default): each step feeds the newest token through the decoder against cached self-attention keys
+        and values (kzv_decode_step); beam steps re-order the cache rows (kzv_decode_reorder).
+        use_cache=False: each step is a decoder-only teacher-forced pass over the whole prefix (kzv_decode_logits), whose
+        position-t logits only depend on ids[:, :t+1] under the causal mask -- the exact cross-check of the cached path.
 
         num_beams == 1: greedy.  num_beams > 1: beam search with HF's bookkeeping (2*num_beams candidates per step, EOS
         candidates ranked >= num_beams dropped, hypothesis score = sum log-prob / len**length_penalty, early stopping once
@@ -271,9 +273,23 @@ class TrOCRModel:
         step_logits = torch.empty(BB, c.vocab, dtype=torch.float32, device=self.device)
         self.forward_loss(px, ids, want_logits=False, seed=0)          # encoder + first decoder pass
 
+        valid = torch.zeros(BB, Lh, dtype=torch.uint8, device=self.device)     # self-attention keys usable (token != pad)
+        posids = torch.empty(BB, dtype=torch.int32, device=self.device)
+        if use_cache:
+            L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")   # (the first call below only needs the encoder)
+
         def logits_at(t):
-            L.check(lib.kzv_set_active_length(self._h, t + 1), "set_active_length")   # later positions are not needed
-            L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
+            if not use_cache:
+                L.check(lib.kzv_set_active_length(self._h, t + 1), "set_active_length")   # later positions are not needed
+                L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
+                return step_logits
+            tok = ids[:, t].contiguous()
+            live = tok != c.pad_id
+            valid[:, t] = live.to(torch.uint8)
+            # RoBERTa position ids (modeling_roberta.py:142-155): cumsum of non-pad tokens + pad_id; prefixes never hold pads
+            posids.copy_(torch.where(live, torch.full_like(tok, t + 1 + c.pad_id), torch.full_like(tok, c.pad_id)).to(torch.int32))
+            L.check(lib.kzv_decode_step(self._h, tok.data_ptr(), posids.data_ptr(), t, valid.data_ptr(), Lh, step_logits.data_ptr(),
+                                        L.stream_handle()), "decode_step")
             return step_logits
 
         if nb == 1:
@@ -344,8 +360,12 @@ class TrOCRModel:
             nb_tok = torch.where(keep, torch.full_like(nb_tok, c.pad_id), nb_tok)
             nb_sc = torch.where(keep, torch.zeros_like(nb_sc), nb_sc)
             done = done | (active & newly)
-            ids = ids[rows.reshape(-1)].contiguous()
+            flat_rows = rows.reshape(-1).contiguous()
+            ids = ids[flat_rows].contiguous()
             ids[:, cur] = nb_tok.reshape(-1)
+            if use_cache:
+                valid = valid[flat_rows].contiguous()
+                L.check(lib.kzv_decode_reorder(self._h, flat_rows.data_ptr(), cur, L.stream_handle()), "decode_reorder")
             beam_scores = nb_sc
             cur += 1
             if bool(done.all()):

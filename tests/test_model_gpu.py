@@ -222,7 +222,9 @@ def test_generate_is_consistent_and_overfit_model_reproduces_labels(tmp_path):
             tok = int(gen[b, t + 1])
             if tok == cfg.pad_id:
                 break
-            assert int(logits[b, t].argmax()) == tok
+            # the argmax of the teacher-forced logits, up to the stated logit tolerance (untrained logits are nearly flat;
+            # the cached step computes attention in fp32 instead of through bf16 MFMA fragments)
+            assert float(logits[b, t].max() - logits[b, t, tok]) < LOGIT_TOL
     # (2) memorise, then decode
     opt = m.configure_optimizers()
     opt.lr = 5e-3
@@ -240,6 +242,47 @@ def test_generate_is_consistent_and_overfit_model_reproduces_labels(tmp_path):
         return "".join(chars[t - 5] for t in ids if t >= 5)
     cers = [m.calculate_cer(text(gen[b]), text(lab[b])) for b in range(4)]
     assert cers == [0.0, 0.0, 0.0, 0.0], cers
+
+
+def test_kv_cached_step_equals_the_prefix_recompute(tmp_path):
+    """kzv_decode_step (one token against cached keys / values) against kzv_decode_logits (teacher-forced pass over the
+    whole prefix) on the same ids, every step, including rows that have already ended (padding), and after a beam-style
+    re-ordering of the cache rows; then the two generate() modes end to end (greedy and beam)."""
+    import ctypes as C
+    from kzv import _lib as L
+    cfg = _no_dropout(tiny_config())
+    m = _make(cfg, tmp_path, 9)
+    m.eval()
+    B, Lh = 6, 14
+    px, lab = synthetic_batch(cfg, B, Lh, seed=4, min_chars=2, max_chars=12)
+    ids = torch.from_numpy(lab).cuda()
+    ids[:, 0] = cfg.bos_id
+    pxt = torch.from_numpy(px).cuda()
+    lib = L.load()
+    m.forward_loss(pxt, ids, want_logits=False, seed=0)
+    a = torch.empty(B, cfg.vocab, device="cuda"); b = torch.empty(B, cfg.vocab, device="cuda")
+    valid = torch.zeros(B, Lh, dtype=torch.uint8, device="cuda")
+    posids = torch.empty(B, dtype=torch.int32, device="cuda")
+    perm = torch.tensor([2, 0, 1, 5, 4, 3], device="cuda")
+    for t in range(Lh - 1):
+        if t == 6:          # beam-style re-ordering: row r continues from former row perm[r]
+            ids = ids[perm].contiguous(); valid = valid[perm].contiguous()
+            L.check(lib.kzv_decode_reorder(m._h, perm.data_ptr(), t, L.stream_handle()), "reorder")
+        tok = ids[:, t].contiguous()
+        live = tok != cfg.pad_id
+        valid[:, t] = live.to(torch.uint8)
+        posids.copy_(torch.where(live, torch.full_like(tok, t + 1 + cfg.pad_id), torch.full_like(tok, cfg.pad_id)).to(torch.int32))
+        L.check(lib.kzv_decode_step(m._h, tok.data_ptr(), posids.data_ptr(), t, valid.data_ptr(), Lh, a.data_ptr(), L.stream_handle()), "step")
+        L.check(lib.kzv_set_active_length(m._h, t + 1), "len")
+        L.check(lib.kzv_decode_logits(m._h, ids.data_ptr(), t, b.data_ptr(), L.stream_handle()), "logits")
+        torch.cuda.synchronize()
+        rows = live.cpu().numpy()                                   # rows whose newest token is padding have no defined output
+        assert not rows.any() or np.abs((a - b).cpu().numpy()[rows]).max() < 2e-2, t
+    for beams in (1, 3):
+        g1 = m.generate(pxt, max_length=Lh, num_beams=beams, early_stopping=False, use_cache=True).cpu()
+        g0 = m.generate(pxt, max_length=Lh, num_beams=beams, early_stopping=False, use_cache=False).cpu()
+        w = min(g0.shape[1], g1.shape[1])
+        assert float((g0[:, :w] == g1[:, :w]).float().mean()) > 0.9     # untrained, nearly flat logits: rare argmax ties may flip
 
 
 @pytest.mark.parametrize("B,L,kw", [
