@@ -125,6 +125,7 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
         cb.on_fit_start(model)
     gstep = 0
     history = []
+    best, save_top_k = [], 3          # (val_loss, path) of the kept checkpoints
     n_batches = len(train_loader)
     val_every = max(1, int(n_batches * val_check_interval)) if val_loader is not None else 0
     for epoch in range(max_epochs):
@@ -154,8 +155,20 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
                 if rank == 0:
                     log(f"epoch {epoch} step {gstep} val_loss {vl:.4f}")
                     if ckpt_dir:
-                        os.makedirs(ckpt_dir, exist_ok=True)
-                        save_checkpoint(model, opt, os.path.join(ckpt_dir, f"trocr-epoch={epoch:02d}-val_loss={vl:.2f}.ckpt"), epoch, gstep, callbacks)
+                        # ModelCheckpoint(monitor="val_loss", save_top_k=3) of scripts/train_trocr.py:136-143: keep the three
+                        # best, write only when the new one ranks among them
+                        if len(best) < save_top_k or vl < best[-1][0]:
+                            os.makedirs(ckpt_dir, exist_ok=True)
+                            path = os.path.join(ckpt_dir, f"trocr-epoch={epoch:02d}-val_loss={vl:.2f}.ckpt")
+                            k = 1
+                            while os.path.exists(path):        # Lightning's -v1, -v2 suffixes for equal names
+                                path = os.path.join(ckpt_dir, f"trocr-epoch={epoch:02d}-val_loss={vl:.2f}-v{k}.ckpt"); k += 1
+                            save_checkpoint(model, opt, path, epoch, gstep, callbacks)
+                            best.append((vl, path)); best.sort(key=lambda e: e[0])
+                            for _, stale in best[save_top_k:]:
+                                if os.path.exists(stale):
+                                    os.remove(stale)
+                            del best[save_top_k:]
             if 0 < max_steps <= gstep:
                 break
         torch.cuda.synchronize()
