@@ -110,8 +110,9 @@ def main(argv=None):
     if args.device_preprocess and not args.synthetic:
         from .preprocess import DevicePreprocessor
         pre = DevicePreprocessor(tuple(args.image_size), device=f"cuda:{local}")
-    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, drop_last=True, preprocessor=pre)
-    val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world, preprocessor=pre)
+    nw = 0 if args.synthetic else max(0, args.num_workers)      # decode (and, without --device_preprocess, resize) in worker processes
+    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, drop_last=True, num_workers=nw, preprocessor=pre)
+    val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world, num_workers=nw, preprocessor=pre)
     if rank == 0:
         print(f"Train samples: {len(train_ds)}\nVal samples: {len(val_ds)}\nParameters: {model.num_parameters():,}")
     cbs = []
