@@ -7,9 +7,12 @@
  *
  * Conventions: every function returns 0 on success, a negative KZV_E_* code on error and records
  * a message readable through kzv_last_error().  All pointers named d_* are DEVICE pointers owned
- * by the caller (torch tensors in the Python host); the library never allocates device memory and
- * keeps no global state besides the last-error string and one 4 KiB device page of zeros (allocated on
- * first use; LDS-DMA loads of out-of-range tile rows are pointed at it).  `stream` is a hipStream_t passed as void*.
+ * by the caller (torch tensors in the Python host): parameters, gradients, optimizer state and one workspace
+ * sized by kzv_workspace_bytes.  The library itself allocates only small or grow-only scratch on the current device,
+ * kept for the life of the process (one device per process): a 4 KiB page of zeros (LDS-DMA loads of out-of-range
+ * tile rows are pointed at it), the LayerNorm gamma/beta partial rows (512 KiB), the gemm_tn256 partial-tile
+ * workspace (<= 66 MB) and, per model handle, the KV cache of kzv_decode_step (freed by kzv_model_destroy).
+ * Other global state: the last-error string, the profiling slots and the CU reserve.  `stream` is a hipStream_t passed as void*.
  * One model handle per process/GPU; a handle is not re-entrant.
  */
 #ifndef KZV_H
@@ -119,6 +122,8 @@ typedef struct kzv_opt_step {
     int32_t adaptive;    /* 1 once rho_t > 4 (use v), else plain (silent) step */
     float max_grad_norm; /* <= 0 disables clipping */
     float grad_scale;    /* multiplied into grads before everything (1/world for DDP mean) */
+    float one_minus_beta2; /* 1 - beta2 evaluated in double on the host, as torch's addcmul_(value=1 - beta2) does: in fp32
+                            * 1.f - 0.999f is off by 1.3e-5 relative, a bias on every second-moment entry */
 } kzv_opt_step;
 int kzv_grad_sqnorm(const float* d_grads, int64_t n, float* d_out1, float* d_scratch, void* stream);
 int kzv_clip_and_step(float* d_params, float* d_z, float* d_v, const float* d_grads, int64_t n,
@@ -187,6 +192,29 @@ int kzv_prof_enable(int on, int capacity);
 int kzv_prof_select(unsigned kind_mask);
 int kzv_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches);
 uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
+
+/* Dropout call sites of the training step (nn.Dropout / F.dropout in the reference).  kzv_forward_loss(train=1, seed) keys
+ * site s with kzv_drop_key(seed, s); backward regenerates the same masks from the same keys (nothing is stored).
+ *   KZV_SITE_ENC_EMB           ViTEncoder dropout on cat(cls, patches) + pos            (trocr_model.py:190)      [B*Se, He]
+ *   KZV_SITE_ENC_LAYER(i, 0)   attention-probability dropout of ViT layer i            (HF modeling_vit.py:184)  [B*heads*Sq, Sk]
+ *   KZV_SITE_ENC_LAYER(i, 1)   ViTLayer.dropout on the attention block's output        (HF modeling_vit.py:276)  [B*Se, He]
+ *   KZV_SITE_ENC_LAYER(i, 2)   ViTLayer.dropout on the MLP output                      (HF modeling_vit.py:283)  [B*Se, He]
+ *   KZV_SITE_DEC_EMB           RobertaEmbeddings.dropout                               (HF modeling_roberta.py:120) [B*T, Hd]
+ *   KZV_SITE_DEC_LAYER(i, 0/2) self / cross attention-probability dropout              (HF modeling_roberta.py:178)
+ *   KZV_SITE_DEC_LAYER(i, 1/3) RobertaSelfOutput.dropout of the self / cross block     (HF modeling_roberta.py:338)
+ *   KZV_SITE_DEC_LAYER(i, 4)   RobertaOutput.dropout (FFN)                             (HF modeling_roberta.py:396)
+ * Element index of a [rows, cols] hidden site: row * cols + col; of an attention site: ((b * heads + h) * Sq + q) * Sk_even
+ * + key with Sk_even = (Sk + 1) & ~1.  Rows are token rows of the PACKED decoder ([B, t_active], kzv_set_active_length). */
+#define KZV_SITE_ENC_EMB 1u
+#define KZV_SITE_ENC_LAYER(i, k) (16u + 4u * (uint32_t)(i) + (uint32_t)(k))
+#define KZV_SITE_DEC_EMB 1000u
+#define KZV_SITE_DEC_LAYER(i, k) (1016u + 8u * (uint32_t)(i) + (uint32_t)(k))
+
+/* Debug / parity entry (mask replay): writes the multiplier (0 or 1/P(keep)) the kernels apply to element
+ * index row * ld_index + col under `key` and drop probability p, for row < rows, col < cols: d_out fp32 [rows, cols].
+ * Uses the same device hash as every fused dropout epilogue, so a test can hand the exact masks of a training step to the
+ * CPU oracle and compare logits, loss and every gradient with dropout ON. */
+int kzv_debug_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t ld_index, float* d_out, void* stream);
 
 /* Data-parallel runs: the GEMM kernels that put exactly one workgroup on every CU (persistent gemm_nt256p, gemm_tn256)
  * double their time when a concurrently running collective holds a few CUs.  With n > 0 the launchers leave n CUs

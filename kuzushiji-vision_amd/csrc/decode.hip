@@ -2,7 +2,8 @@
 //
 // Replaces, for generation only, the per-step work of HF RobertaSelfAttention / RobertaCrossAttention with `use_cache=True`
 // (modeling_roberta.py:186-326) as driven by `decoder.generate` (src/models/trocr_model.py:306-316).  One wave per
-// (sequence, head): every lane scores up to 3 keys (<= 192) against the 64-dim query in fp32, softmax across the wave,
+// (sequence, head): every lane scores up to NU keys (NU = 3: <= 192 keys; NU = 5: <= 320, the reference's default 1024x64
+// columns give 256 cross-attention keys) against the 64-dim query in fp32, softmax across the wave,
 // then lane d accumulates output dimension d over the keys (128-B coalesced V rows).  The self-attention variant also
 // appends this step's key and value to the cache.  Work per step is tiny (B*heads waves); the step is launch-bound.
 #include "kzv_common.h"
@@ -22,8 +23,9 @@ struct DecAttnP {
     float scale;
 };
 
+template <int NU>
 __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
-    __shared__ float prob[192];
+    __shared__ float prob[64 * NU];
     __shared__ float qs[64];
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, lane = threadIdx.x;
     bf16_t* Kb = p.K + (int64_t)b * p.kb + h * 64;
@@ -34,10 +36,10 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
     }
     qs[lane] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + lane]) * p.scale;
     __syncthreads();                              // cache row + query visible to the whole wave
-    float sc[3];
+    float sc[NU];
     float mx = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int j = lane + 64 * u;
         sc[u] = -INFINITY;
         if (j < p.nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) {
@@ -57,11 +59,11 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
     const bool dead = mx == -INFINITY;            // no usable key (a finished, all-pad row): output zeros
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; }
+    for (int u = 0; u < NU; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; }
     sum = wave_sum(sum);
     const float inv = dead ? 0.f : 1.f / sum;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) if (lane + 64 * u < 192) prob[lane + 64 * u] = sc[u] * inv;
+    for (int u = 0; u < NU; ++u) prob[lane + 64 * u] = sc[u] * inv;
     __syncthreads();
     float o = 0.f;
     for (int j = 0; j < p.nkeys; ++j) o += prob[j] * bf2f(Vb[(int64_t)j * p.kj + lane]);
@@ -85,9 +87,10 @@ __global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
                     int append_at, hipStream_t s) {
-    if (nkeys < 1 || nkeys > 192) return kzv_fail(KZV_E_ARG, "attn_decode: 1..192 keys");
+    if (nkeys < 1 || nkeys > 320) return kzv_fail(KZV_E_ARG, "attn_decode: 1..320 keys");
     DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f};
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(B * heads), dim3(64), 0, s, p);
+    if (nkeys <= 192) hipLaunchKernelGGL(attn_decode_kernel<3>, dim3(B * heads), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(attn_decode_kernel<5>, dim3(B * heads), dim3(64), 0, s, p);
     return kzv_check_launch("attn_decode");
 }
 

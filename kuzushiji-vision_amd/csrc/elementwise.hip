@@ -285,6 +285,15 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const KzvCastDesc* __
     }
 }
 
+// debug / parity: the multiplier every fused dropout applies to element index row * ld + col
+__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t rows, int64_t cols, int64_t ld, unsigned thr16, float inv_keep, unsigned key) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const int64_t r = t / cols, c = t - r * cols;
+    const unsigned e = (unsigned)r * (unsigned)ld + (unsigned)c;
+    out[t] = thr16 ? drop_keep(drop_bits(key, e >> 1), e & 1, thr16, inv_keep) : 1.f;
+}
+
 inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 }  // namespace
@@ -361,4 +370,12 @@ int kzv_copy_logits(const float* logits, int64_t ldl, float* out, int rows, int 
 int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s) {
     hipLaunchKernelGGL(cast_weights_kernel, dim3(total_tiles), dim3(256), 0, s, d_desc, ndesc);
     return kzv_check_launch("cast_weights");
+}
+
+extern "C" int kzv_debug_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t ld_index, float* d_out, void* stream) {
+    if (!d_out || rows < 0 || cols < 0 || ld_index < cols) return kzv_fail(KZV_E_ARG, "debug_dropout_mask: bad shape");
+    if (rows * cols == 0) return KZV_OK;
+    unsigned thr; float ik; kzv_drop_params(p, &thr, &ik);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblk(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, d_out, rows, cols, ld_index, thr, ik, key);
+    return kzv_check_launch("debug_dropout_mask");
 }

@@ -242,7 +242,7 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
 }
 
 // dropout site ids (distinct hash keys per call site and layer)
-enum { SITE_ENC_EMB = 1, SITE_ENC_L = 16, SITE_DEC_EMB = 1000, SITE_DEC_L = 1016 };
+enum { SITE_ENC_EMB = KZV_SITE_ENC_EMB, SITE_ENC_L = KZV_SITE_ENC_LAYER(0, 0), SITE_DEC_EMB = KZV_SITE_DEC_EMB, SITE_DEC_L = KZV_SITE_DEC_LAYER(0, 0) };
 inline uint32_t key(const kzv_model* m, uint32_t site) { return kzv_drop_key(m->seed, site); }
 inline float dp(const kzv_model* m, float p) { return m->train ? p : 0.f; }
 

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void clip_step_kernel(float* __restrict__ p, f
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float gr = gg[r] * gs;
-            vv[r] = vv[r] * s.beta2 + (1.f - s.beta2) * gr * gr;
+            vv[r] = vv[r] * s.beta2 + s.one_minus_beta2 * gr * gr;
             float gn = s.adaptive ? gr / (sqrtf(vv[r] * inv_bc2) + s.eps) : gr;
             gn += s.weight_decay * pp[r];
             float y = pp[r] + s.ckp1 * (zz[r] - pp[r]);

@@ -25,7 +25,7 @@ class kzv_config(C.Structure):
 class kzv_opt_step(C.Structure):
     _fields_ = [("lr_t", C.c_float), ("ckp1", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("bias_correction2", C.c_float),
-                ("adaptive", C.c_int32), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float)]
+                ("adaptive", C.c_int32), ("max_grad_norm", C.c_float), ("grad_scale", C.c_float), ("one_minus_beta2", C.c_float)]
 
 
 class kzv_gemm_nt_args(C.Structure):
@@ -92,6 +92,7 @@ SYMBOLS = {
     "kzv_attn_fwd": (C.c_int, [C.POINTER(kzv_attn_args), _P]),
     "kzv_attn_bwd": (C.c_int, [C.POINTER(kzv_attn_args), _P]),
     "kzv_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint32]),
+    "kzv_debug_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "kzv_prof_select": (C.c_int, [C.c_uint]),
     "kzv_set_cu_reserve": (C.c_int, [C.c_int]),

@@ -1,0 +1,101 @@
+"""Token-selection bookkeeping of ``decoder.generate`` as the reference calls it (src/models/trocr_model.py:306-316:
+``max_length=128, num_beams=4, early_stopping=True, pad_token_id, eos_token_id``), separated from the engine so that it can
+be pinned on the CPU against HF's own implementation (tests/test_host_cpu.py runs transformers' ``generate`` on a small
+RobertaForCausalLM and this module on the same step logits).
+
+``generate`` lives in a third-party dependency (transformers; the reference pins 4.57.0, this image holds 5.15.0), not
+under /root/reference; what is restated here is its published algorithm, following transformers/generation/utils.py
+``GenerationMixin._beam_search`` (:3208-3508) and its helpers ``_get_top_k_continuations`` (:3077-3129),
+``_get_running_beams_for_next_iteration`` (:3131-3151), ``_update_finished_beams`` (:3153-3204),
+``_check_early_stop_heuristic`` (:3008-3052), ``_beam_search_has_unfinished_sequences`` (:3055-3075), and the greedy
+branch of ``_sample``:
+
+  * every step ranks the 2*num_beams best continuations of [num_beams x vocab] accumulated log-probabilities;
+  * a continuation "hits a stopping criterion" when its token is EOS or it reaches max_length; only those among the first
+    num_beams ranks may enter the finished list, scored sum-log-prob / generated_length**length_penalty; the finished list
+    keeps the best num_beams by score;
+  * the running beams of the next step are the best num_beams continuations that did NOT hit a stopping criterion;
+  * with early_stopping=True a batch element stops accepting hypotheses once it holds num_beams finished ones, and the
+    loop ends when every batch element is full; with early_stopping=False the loop ends when, for every element, the best
+    running score / current generated length cannot beat its worst finished score;
+  * the result is the best finished hypothesis per element, cropped to the longest one, padded with pad_token_id.
+
+Everything is torch tensor arithmetic on whatever device the logits live on (vectorised over the batch; one host
+synchronisation per step for the loop condition).  ``step(t, flat_ids)`` must return the next-token logits [B*beams, V] of
+position t given ids[:, :t+1]; ``reorder(flat_rows, t)`` is told which former row each row continues from (KV cache).
+"""
+from __future__ import annotations
+
+NEG = -1.0e9
+
+
+def greedy(step, batch: int, max_len: int, pad_id: int, bos_id: int, eos_id: int, device):
+    """``num_beams=1``: argmax per step; finished rows emit padding; stops when every row has emitted EOS."""
+    import torch
+    ids = torch.full((batch, max_len), pad_id, dtype=torch.int64, device=device)
+    ids[:, 0] = bos_id
+    done = torch.zeros(batch, dtype=torch.bool, device=device)
+    n = 1
+    for t in range(max_len - 1):
+        nxt = step(t, ids).argmax(-1)
+        nxt = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+        ids[:, t + 1] = nxt
+        n = t + 2
+        done |= nxt == eos_id
+        if bool(done.all()):
+            break
+    return ids[:, :n]
+
+
+def beam_search(step, reorder, batch: int, num_beams: int, max_len: int, vocab: int, pad_id: int, bos_id: int, eos_id: int,
+                device, early_stopping=True, length_penalty: float = 1.0):
+    import torch
+    B, nb, K = batch, num_beams, 2 * num_beams
+    prompt = 1                                                    # decoder prompt = [BOS]
+    run_seq = torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=device)
+    run_seq[:, :, 0] = bos_id
+    fin_seq = run_seq.clone()
+    run_sc = torch.zeros(B, nb, device=device)
+    run_sc[:, 1:] = NEG                                           # only beam 0 is live at the first step
+    fin_sc = torch.full((B, nb), NEG, device=device)
+    fin_done = torch.zeros(B, nb, dtype=torch.bool, device=device)
+    fin_len = torch.full((B, nb), prompt, dtype=torch.int64, device=device)
+    unsat = torch.ones(B, 1, dtype=torch.bool, device=device)     # "the open beams may still improve the finished ones"
+    top_mask = (torch.arange(K, device=device) < nb).view(1, K)
+    base = (torch.arange(B, device=device) * nb).view(B, 1)
+    cur = prompt
+    while True:
+        logp = torch.log_softmax(step(cur - 1, run_seq.view(B * nb, max_len)).float(), dim=-1)
+        acc = (logp.view(B, nb, vocab) + run_sc.unsqueeze(-1)).view(B, nb * vocab)
+        top_lp, top_ix = acc.topk(K, dim=1)
+        src, tok = top_ix // vocab, top_ix % vocab
+        cand = run_seq.gather(1, src.unsqueeze(-1).expand(B, K, max_len)).clone()
+        cand[:, :, cur] = tok
+        hits = (tok == eos_id) | (cur + 1 >= max_len)
+        # running beams of the next step: the best nb continuations that did not stop
+        nxt_ix = (top_lp + hits.float() * NEG).topk(nb, dim=1)[1]
+        run_seq = cand.gather(1, nxt_ix.unsqueeze(-1).expand(B, nb, max_len))
+        run_sc = (top_lp + hits.float() * NEG).gather(1, nxt_ix)
+        rows = (base + src.gather(1, nxt_ix)).reshape(-1)
+        # finished list: stopped continuations of rank < nb, normalised by the generated length
+        just = hits & top_mask
+        fsc = top_lp / float((cur + 1 - prompt) ** length_penalty)
+        full = fin_done.all(dim=1, keepdim=True) & (early_stopping is True)
+        fsc = fsc + full.float() * NEG + (~unsat).float() * NEG + (~just).float() * NEG
+        m_sc = torch.cat((fin_sc, fsc), dim=1)
+        m_ix = m_sc.topk(nb, dim=1)[1]
+        fin_seq = torch.cat((fin_seq, cand), dim=1).gather(1, m_ix.unsqueeze(-1).expand(B, nb, max_len))
+        fin_sc = m_sc.gather(1, m_ix)
+        fin_done = torch.cat((fin_done, just), dim=1).gather(1, m_ix)
+        fin_len = torch.cat((fin_len, torch.full((B, K), cur + 1, dtype=torch.int64, device=device)), dim=1).gather(1, m_ix)
+        cur += 1
+        # stop test (one host synchronisation per step)
+        best_open = run_sc[:, :1] / float((cur - prompt) ** length_penalty)
+        worst_fin = torch.where(fin_done, fin_sc.min(dim=1, keepdim=True)[0], torch.full_like(fin_sc, NEG))
+        unsat = unsat & (best_open > worst_fin).any(dim=-1, keepdim=True)
+        go_on = unsat.any() & ~(fin_done.all() & (early_stopping is True)) & ~hits.all()
+        if not bool(go_on):
+            break
+        reorder(rows, cur - 1)
+    width = int(fin_len[:, 0].max())
+    return fin_seq[:, 0, :width]

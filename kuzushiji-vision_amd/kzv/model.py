@@ -250,13 +250,11 @@ class TrOCRModel:
         use_cache=False: each step is a decoder-only teacher-forced pass over the whole prefix (kzv_decode_logits), whose
         position-t logits only depend on ids[:, :t+1] under the causal mask -- the exact cross-check of the cached path.
 
-        num_beams == 1: greedy.  num_beams > 1: beam search with HF's bookkeeping (2*num_beams candidates per step, EOS
-        candidates ranked >= num_beams dropped, hypothesis score = sum log-prob / len**length_penalty, early stopping once
-        num_beams hypotheses are finished) -- what the reference asks of ``decoder.generate(num_beams=4,
-        early_stopping=True)`` (trocr_model.py:306-316).  Parity with HF's implementation is UNPINNED.
-        The beam bookkeeping (top-k, log-softmax over [B*beams, V], hypothesis lists) is torch glue on the device, vectorised
-        over the batch."""
+        Token selection (greedy for num_beams == 1, else beam search with HF's rules) is kzv/beam.py, pinned on the CPU
+        against transformers' own ``generate``; the reference asks for ``num_beams=4, early_stopping=True``
+        (trocr_model.py:306-316).  The step logits come from this engine."""
         import torch
+        from . import beam as BM
         c = self.cfg
         px = self._check_inputs(pixel_values)
         B = px.shape[0]
@@ -268,23 +266,25 @@ class TrOCRModel:
         if nb > 1:
             px = px.repeat_interleave(nb, dim=0)
         BB = B * nb
-        ids = torch.full((BB, Lh), c.pad_id, dtype=torch.int64, device=self.device)
-        ids[:, 0] = c.bos_id
+        ids0 = torch.full((BB, Lh), c.pad_id, dtype=torch.int64, device=self.device)
+        ids0[:, 0] = c.bos_id
         step_logits = torch.empty(BB, c.vocab, dtype=torch.float32, device=self.device)
-        self.forward_loss(px, ids, want_logits=False, seed=0)          # encoder + first decoder pass
-
-        valid = torch.zeros(BB, Lh, dtype=torch.uint8, device=self.device)     # self-attention keys usable (token != pad)
+        self.forward_loss(px, ids0, want_logits=False, seed=0)          # encoder + cross K/V (and a first decoder pass)
+        state = {"valid": torch.zeros(BB, Lh, dtype=torch.uint8, device=self.device)}   # self-attention keys usable (token != pad)
         posids = torch.empty(BB, dtype=torch.int32, device=self.device)
         if use_cache:
-            L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")   # (the first call below only needs the encoder)
+            L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")
 
-        def logits_at(t):
+        def step(t, ids):
             if not use_cache:
+                ids = ids.contiguous()
+                state["ids"] = ids                                        # keep alive until the kernels have run
                 L.check(lib.kzv_set_active_length(self._h, t + 1), "set_active_length")   # later positions are not needed
                 L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
                 return step_logits
             tok = ids[:, t].contiguous()
             live = tok != c.pad_id
+            valid = state["valid"]
             valid[:, t] = live.to(torch.uint8)
             # RoBERTa position ids (modeling_roberta.py:142-155): cumsum of non-pad tokens + pad_id; prefixes never hold pads
             posids.copy_(torch.where(live, torch.full_like(tok, t + 1 + c.pad_id), torch.full_like(tok, c.pad_id)).to(torch.int32))
@@ -292,95 +292,19 @@ class TrOCRModel:
                                         L.stream_handle()), "decode_step")
             return step_logits
 
-        if nb == 1:
-            done = torch.zeros(B, dtype=torch.bool, device=self.device)
-            n = 1
-            for t in range(Lh - 1):
-                nxt = logits_at(t).argmax(-1)
-                nxt = torch.where(done, torch.full_like(nxt, c.pad_id), nxt)
-                ids[:, t + 1] = nxt
-                n = t + 2
-                done |= nxt == c.eos_id
-                if bool(done.all()):
-                    break
-            self.training = was
-            return ids[:, :n]
-
-        # Beam bookkeeping on the device, vectorised over the batch (HF's rules; one host sync per step for the stop test):
-        #   candidates = top 2*nb of [nb beams x V]; an EOS candidate counts as a finished hypothesis iff its rank < nb;
-        #   the first nb non-EOS candidates (rank order) become the new beams (each beam yields at most one EOS candidate,
-        #   so at least nb non-EOS ones exist); every batch element keeps its best nb hypotheses.
-        dev = self.device
-        NEG = -1e30
-        beam_scores = torch.zeros(B, nb, device=dev)
-        beam_scores[:, 1:] = -1e9
-        hyp_scores = torch.full((B, nb), NEG, device=dev)
-        hyp_ids = torch.full((B, nb, Lh), c.pad_id, dtype=torch.int64, device=dev)
-        hyp_len = torch.zeros(B, nb, dtype=torch.int64, device=dev)
-        hyp_cnt = torch.zeros(B, dtype=torch.int64, device=dev)
-        done = torch.zeros(B, dtype=torch.bool, device=dev)
-        rank = torch.arange(2 * nb, device=dev).view(1, -1)
-        base = (torch.arange(B, device=dev) * nb).view(-1, 1)
-        cur = 1
-
-        def merge(h_s, h_i, h_l, c_s, c_i, c_l):
-            """keep the best nb of the union (existing first, so ties keep the earlier hypothesis like a stable sort)"""
-            sc = torch.cat([h_s, c_s], 1)
-            top, idx = sc.topk(nb, dim=1)
-            allid = torch.cat([h_i, c_i], 1)
-            return top, allid.gather(1, idx.unsqueeze(-1).expand(-1, -1, Lh)), torch.cat([h_l, c_l], 1).gather(1, idx)
-
-        for t in range(Lh - 1):
-            lp = torch.log_softmax(logits_at(t), dim=-1) + beam_scores.view(-1, 1)
-            top_s, top_i = lp.view(B, nb * c.vocab).topk(2 * nb, dim=1)
-            beam, tok = top_i // c.vocab, top_i % c.vocab
-            is_eos = tok == c.eos_id
-            active = ~done
-            # finished hypotheses of this step: EOS candidates of rank < nb (sequence = the beam's ids so far, length cur)
-            take = is_eos[:, :nb] & active.view(-1, 1)
-            c_s = torch.where(take, top_s[:, :nb] / (cur ** length_penalty), torch.full_like(top_s[:, :nb], NEG))
-            c_i = ids.view(B, nb, Lh).gather(1, beam[:, :nb].unsqueeze(-1).expand(-1, -1, Lh))
-            c_l = torch.full((B, nb), cur, dtype=torch.int64, device=dev)
-            hyp_scores, hyp_ids, hyp_len = merge(hyp_scores, hyp_ids, hyp_len, c_s, c_i, c_l)
-            hyp_cnt = torch.clamp(hyp_cnt + take.sum(1), max=nb)
-            # new beams: the first nb non-EOS candidates in rank order
-            non = ~is_eos
-            pos = non.cumsum(1) - 1
-            sel = non & (pos < nb)
-            order = torch.where(sel, pos, torch.full_like(pos, 2 * nb)).argsort(1)[:, :nb]      # candidate index of new beam k
-            nb_beam, nb_tok, nb_sc = beam.gather(1, order), tok.gather(1, order), top_s.gather(1, order)
-            # finished batch elements keep their rows and write padding (scores irrelevant from here on)
-            full = hyp_cnt >= nb
-            if early_stopping:
-                newly = full
-            else:   # HF heuristic: stop when even the best open beam cannot beat the worst kept hypothesis
-                newly = full & (hyp_scores[:, -1] >= top_s[:, 0] / ((cur + 1) ** length_penalty))
-            keep = done.view(-1, 1)
-            rows = torch.where(keep, base.expand(-1, nb), base + nb_beam)
-            nb_tok = torch.where(keep, torch.full_like(nb_tok, c.pad_id), nb_tok)
-            nb_sc = torch.where(keep, torch.zeros_like(nb_sc), nb_sc)
-            done = done | (active & newly)
-            flat_rows = rows.reshape(-1).contiguous()
-            ids = ids[flat_rows].contiguous()
-            ids[:, cur] = nb_tok.reshape(-1)
+        def reorder(rows, n_keys):
             if use_cache:
-                valid = valid[flat_rows].contiguous()
-                L.check(lib.kzv_decode_reorder(self._h, flat_rows.data_ptr(), cur, L.stream_handle()), "decode_reorder")
-            beam_scores = nb_sc
-            cur += 1
-            if bool(done.all()):
-                break
-        # open beams of unfinished batch elements compete as hypotheses of their current length
-        c_s = torch.where(done.view(-1, 1), torch.full_like(beam_scores, NEG), beam_scores / (cur ** length_penalty))
-        c_l = torch.full((B, nb), cur, dtype=torch.int64, device=dev)
-        hyp_scores, hyp_ids, hyp_len = merge(hyp_scores, hyp_ids, hyp_len, c_s, ids.view(B, nb, Lh), c_l)
-        width = min(cur + 1, Lh)
-        best_ids, best_len = hyp_ids[:, 0, :width].clone(), hyp_len[:, 0]
-        col = torch.arange(width, device=dev).view(1, -1)
-        out = torch.where(col < best_len.view(-1, 1), best_ids, torch.full_like(best_ids, c.pad_id))
-        out = torch.where((col == best_len.view(-1, 1)) & (best_len.view(-1, 1) < width), torch.full_like(out, c.eos_id), out)
-        self.training = was
-        return out
+                rows = rows.contiguous()
+                state["valid"] = state["valid"][rows].contiguous()
+                L.check(lib.kzv_decode_reorder(self._h, rows.data_ptr(), n_keys, L.stream_handle()), "decode_reorder")
+
+        try:
+            if nb == 1:
+                return BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device)
+            return BM.beam_search(step, reorder, B, nb, Lh, c.vocab, c.pad_id, c.bos_id, c.eos_id, self.device,
+                                  early_stopping=early_stopping, length_penalty=length_penalty)
+        finally:
+            self.training = was
 
     # ------------------------------------------------------------------ Lightning-shaped steps (:323-398)
     def training_step(self, batch, batch_idx):
@@ -396,10 +320,12 @@ class TrOCRModel:
         val = float(loss.item())
         self.log("val_loss", val)
         if batch_idx < 5 and self.tokenizer is not None:
-            gen = self.generate(batch["pixel_values"][:1])
-            pred = self.tokenizer.batch_decode(gen, skip_special_tokens=True)[0]
-            tgt = self.tokenizer.batch_decode(batch["labels"][:1], skip_special_tokens=True)[0]
-            self.log("val_cer", self.calculate_cer(pred, tgt))
+            # trocr_model.py:345-358: self(pixel_values) = beam-4 generation of the whole batch, CER of sample 0
+            gen = self(batch["pixel_values"])["generated_ids"]
+            pred = self.tokenizer.batch_decode(gen, skip_special_tokens=True)
+            tgt = self.tokenizer.batch_decode(batch["labels"], skip_special_tokens=True)
+            if len(pred) > 0 and len(tgt) > 0:
+                self.log("val_cer", self.calculate_cer(pred[0], tgt[0]))
         self.training = was
         return val
 
@@ -410,7 +336,7 @@ class TrOCRModel:
         val = float(loss.item())
         self.log("test_loss", val)
         if self.tokenizer is not None:
-            gen = self.generate(batch["pixel_values"])
+            gen = self(batch["pixel_values"])["generated_ids"]           # trocr_model.py:373: beam 4, max_length 128
             preds = self.tokenizer.batch_decode(gen, skip_special_tokens=True)
             tgts = self.tokenizer.batch_decode(batch["labels"], skip_special_tokens=True)
             cers = [self.calculate_cer(p, t) for p, t in zip(preds, tgts)]
@@ -454,7 +380,7 @@ class TrOCRModel:
 
     def decode_predictions(self, pixel_values) -> list[str]:
         self.eval()
-        gen = self.generate(pixel_values)
+        gen = self(pixel_values)["generated_ids"]                         # trocr_model.py:457
         return self.tokenizer.batch_decode(gen, skip_special_tokens=True)
 
 

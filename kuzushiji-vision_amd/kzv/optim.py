@@ -70,7 +70,7 @@ class RAdamScheduleFree:
             L.check(lib.kzv_grad_sqnorm(m.flat_grads.data_ptr(), n, self._sq.data_ptr(), self._scratch.data_ptr(), st), "grad_sqnorm")
         s = L.kzv_opt_step(lr_t=lr, ckp1=ckp1, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
                            weight_decay=self.weight_decay, bias_correction2=bc2, adaptive=int(adaptive),
-                           max_grad_norm=max_grad_norm, grad_scale=grad_scale)
+                           max_grad_norm=max_grad_norm, grad_scale=grad_scale, one_minus_beta2=1.0 - self.beta2)
         L.check(lib.kzv_clip_and_step(m.flat_params.data_ptr(), self.z.data_ptr(), self.v.data_ptr(),
                                       m.flat_grads.data_ptr(), n, self._sq.data_ptr(), C.byref(s), st), "clip_and_step")
         m.sync_weights()

@@ -36,13 +36,23 @@ def _heads(x, nh):  # [B,S,H] -> [B,nh,S,d]   (HF modeling_vit.py:212-217)
     return x.view(B, S, nh, H // nh).transpose(1, 2)
 
 
-def _attention(q, k, v, nh, add_mask=None):
-    """softmax(q k^T * d^-0.5 + mask) v  -- HF modeling_vit.py:164-189 / modeling_roberta.py:158-183."""
+def _drop(x, masks, name):
+    """nn.Dropout / F.dropout in training mode with an EXPLICIT mask: ``masks[name]`` holds the multiplier of every
+    element (0 for dropped, 1/P(keep) for kept), shaped like x.  masks=None or a missing name = dropout off (eval).
+    Lets a test replay the exact masks the HIP kernels drew (kzv_debug_dropout_mask) through the reference's arithmetic."""
+    if masks is None or name not in masks:
+        return x
+    return x * masks[name].to(x.dtype).reshape(x.shape)
+
+
+def _attention(q, k, v, nh, add_mask=None, masks=None, site=None):
+    """softmax(q k^T * d^-0.5 + mask) v  -- HF modeling_vit.py:164-189 / modeling_roberta.py:158-183;
+    probability dropout at modeling_vit.py:184 / modeling_roberta.py:178 (mask [B, nh, Sq, Sk])."""
     qh, kh, vh = _heads(q, nh), _heads(k, nh), _heads(v, nh)
     s = torch.matmul(qh, kh.transpose(2, 3)) * (qh.shape[-1] ** -0.5)
     if add_mask is not None:
         s = s + add_mask
-    p = torch.softmax(s, dim=-1)
+    p = _drop(torch.softmax(s, dim=-1), masks, site)
     o = torch.matmul(p, vh)  # [B,nh,S,d]
     B, _, S, _ = o.shape
     return o.transpose(1, 2).reshape(B, S, -1)
@@ -58,14 +68,16 @@ def patch_embed(cfg, sd, pixel_values):
     return x.flatten(2).transpose(1, 2)
 
 
-def encoder_forward(cfg, sd, pixel_values, stages=None):
-    """ViTEncoder.forward -- src/models/trocr_model.py:169-202; layers = HF ViTLayer (modeling_vit.py:257-286)."""
+def encoder_forward(cfg, sd, pixel_values, stages=None, masks=None):
+    """ViTEncoder.forward -- src/models/trocr_model.py:169-202; layers = HF ViTLayer (modeling_vit.py:257-286).
+    Dropout sites (training): embeddings :190 ("enc_emb"), attention probabilities ("enc{i}_attn"), ViTLayer.dropout after
+    the attention block (modeling_vit.py:276, "enc{i}_o") and after the MLP (:283, "enc{i}_mlp")."""
     B = pixel_values.shape[0]
     x = patch_embed(cfg, sd, pixel_values)
     if stages is not None:
         stages["patch_embed"] = x
     cls = sd["encoder.cls_token"].expand(B, -1, -1)
-    x = torch.cat((cls, x), dim=1) + sd["encoder.position_embeddings"]   # :183-187 (dropout off)
+    x = _drop(torch.cat((cls, x), dim=1) + sd["encoder.position_embeddings"], masks, "enc_emb")   # :183-190
     if stages is not None:
         stages["enc_embed"] = x
     nh = cfg.enc_heads
@@ -75,11 +87,11 @@ def encoder_forward(cfg, sd, pixel_values, stages=None):
         q = F.linear(h, sd[p + "attention.attention.query.weight"], sd[p + "attention.attention.query.bias"])
         k = F.linear(h, sd[p + "attention.attention.key.weight"], sd[p + "attention.attention.key.bias"])
         v = F.linear(h, sd[p + "attention.attention.value.weight"], sd[p + "attention.attention.value.bias"])
-        a = _attention(q, k, v, nh)
-        x = x + F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        a = _attention(q, k, v, nh, None, masks, f"enc{i}_attn")
+        x = x + _drop(F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"]), masks, f"enc{i}_o")
         h = _ln(x, sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"], cfg.ln_eps)
         h = _gelu(F.linear(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
-        x = x + F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        x = x + _drop(F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]), masks, f"enc{i}_mlp")
         if stages is not None:
             stages[f"enc_layer{i}"] = x
     x = _ln(x, sd["encoder.layernorm.weight"], sd["encoder.layernorm.bias"], cfg.ln_eps)  # :197
@@ -95,13 +107,16 @@ def position_ids(ids, pad_id):
     return torch.cumsum(m, dim=1) * m + pad_id
 
 
-def decoder_forward(cfg, sd, input_ids, enc, stages=None):
+def decoder_forward(cfg, sd, input_ids, enc, stages=None, masks=None):
     """RobertaForCausalLM(is_decoder, add_cross_attention) teacher-forced forward.
 
     embeddings: HF modeling_roberta.py:75-122; layer (post-LN): :421-464 with self-attn :186-250,
     cross-attn :253-326, output blocks :329-340 / :372-398; masks :645-680 (causal AND key != pad,
     no encoder mask); head :877-893.  Attention mask built from ids as in
     src/models/trocr_model.py:278.
+    Dropout sites (training): embeddings :120 ("dec_emb"); per layer the self / cross attention probabilities :178
+    ("dec{i}_sa", "dec{i}_ca"), RobertaSelfOutput.dropout :338 of both blocks ("dec{i}_sa_o", "dec{i}_ca_o") and
+    RobertaOutput.dropout :396 ("dec{i}_ffn").
     """
     r = "decoder.roberta."
     B, T = input_ids.shape
@@ -109,7 +124,7 @@ def decoder_forward(cfg, sd, input_ids, enc, stages=None):
     x = (sd[r + "embeddings.word_embeddings.weight"][input_ids]
          + sd[r + "embeddings.token_type_embeddings.weight"][0]
          + sd[r + "embeddings.position_embeddings.weight"][pos])
-    x = _ln(x, sd[r + "embeddings.LayerNorm.weight"], sd[r + "embeddings.LayerNorm.bias"], cfg.ln_eps)
+    x = _drop(_ln(x, sd[r + "embeddings.LayerNorm.weight"], sd[r + "embeddings.LayerNorm.bias"], cfg.ln_eps), masks, "dec_emb")
     if stages is not None:
         stages["dec_embed"] = x
     neg = torch.finfo(x.dtype).min
@@ -122,17 +137,17 @@ def decoder_forward(cfg, sd, input_ids, enc, stages=None):
         q = F.linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"])
         k = F.linear(x, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"])
         v = F.linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"])
-        a = _attention(q, k, v, nh, mask)
-        a = F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        a = _attention(q, k, v, nh, mask, masks, f"dec{i}_sa")
+        a = _drop(F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"]), masks, f"dec{i}_sa_o")
         x = _ln(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
         q = F.linear(x, sd[p + "crossattention.self.query.weight"], sd[p + "crossattention.self.query.bias"])
         k = F.linear(enc, sd[p + "crossattention.self.key.weight"], sd[p + "crossattention.self.key.bias"])
         v = F.linear(enc, sd[p + "crossattention.self.value.weight"], sd[p + "crossattention.self.value.bias"])
-        a = _attention(q, k, v, nh)
-        a = F.linear(a, sd[p + "crossattention.output.dense.weight"], sd[p + "crossattention.output.dense.bias"])
+        a = _attention(q, k, v, nh, None, masks, f"dec{i}_ca")
+        a = _drop(F.linear(a, sd[p + "crossattention.output.dense.weight"], sd[p + "crossattention.output.dense.bias"]), masks, f"dec{i}_ca_o")
         x = _ln(a + x, sd[p + "crossattention.output.LayerNorm.weight"], sd[p + "crossattention.output.LayerNorm.bias"], cfg.ln_eps)
         h = _gelu(F.linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
-        h = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        h = _drop(F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]), masks, f"dec{i}_ffn")
         x = _ln(h + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], cfg.ln_eps)
         if stages is not None:
             stages[f"dec_layer{i}"] = x
@@ -142,16 +157,17 @@ def decoder_forward(cfg, sd, input_ids, enc, stages=None):
     return F.linear(h, sd[r + "embeddings.word_embeddings.weight"], sd["decoder.lm_head.bias"])
 
 
-def forward(cfg, sd, pixel_values, labels, stages=None):
-    """TrOCRModel.forward, training branch -- src/models/trocr_model.py:258-297.  Returns (logits, loss)."""
-    enc = encoder_forward(cfg, sd, pixel_values, stages)
+def forward(cfg, sd, pixel_values, labels, stages=None, masks=None):
+    """TrOCRModel.forward, training branch -- src/models/trocr_model.py:258-297.  Returns (logits, loss).
+    ``masks`` (optional): explicit dropout multipliers per site, see _drop; None = eval mode."""
+    enc = encoder_forward(cfg, sd, pixel_values, stages, masks)
     if cfg.has_proj:
         enc = F.linear(enc, sd["encoder_decoder_proj.weight"], sd["encoder_decoder_proj.bias"])  # :269
     if stages is not None:
         stages["proj_out"] = enc
     ids = labels[:, :-1].contiguous()       # :274
     tgt = labels[:, 1:].contiguous()        # :275
-    logits = decoder_forward(cfg, sd, ids, enc, stages)
+    logits = decoder_forward(cfg, sd, ids, enc, stages, masks)
     loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), tgt.reshape(-1), ignore_index=cfg.pad_id)  # :256,:292
     return logits, loss
 
@@ -168,11 +184,13 @@ def leaf_state_dict(sd_np, dtype=torch.float32, requires_grad=True):
     return out
 
 
-def forward_backward(cfg, sd_np, pixel_values, labels, dtype=torch.float32, want_stages=False):
+def forward_backward(cfg, sd_np, pixel_values, labels, dtype=torch.float32, want_stages=False, masks=None):
     """One teacher-forced step; returns dict(logits, loss, grads{hf_name: ndarray}, stages)."""
     sd = leaf_state_dict(sd_np, dtype)
     stages = {} if want_stages else None
-    logits, loss = forward(cfg, sd, torch.as_tensor(pixel_values).to(dtype), torch.as_tensor(labels), stages)
+    if masks is not None:
+        masks = {k: torch.as_tensor(v) for k, v in masks.items()}
+    logits, loss = forward(cfg, sd, torch.as_tensor(pixel_values).to(dtype), torch.as_tensor(labels), stages, masks)
     loss.backward()
     grads = {k: (v.grad.detach().numpy() if v.grad is not None else None) for k, v in sd.items()}
     return {"logits": logits.detach().numpy(), "loss": float(loss.detach()), "grads": grads,
@@ -269,3 +287,49 @@ def calculate_cer(pred_text: str, target_text: str) -> float:
     if len(target_text) == 0:
         return 1.0 if len(pred_text) > 0 else 0.0
     return levenshtein(pred_text, target_text) / len(target_text)
+
+
+# ---- greedy decoding by step-wise forward -------------------------
+def greedy_stepwise(cfg, sd, pixel_values, max_length):
+    """Greedy decoding from BOS through the TRAINING-branch forward, one position per call: token t+1 = argmax of the
+    teacher-forced logits at position t over the prefix so far (under the causal AND key-not-pad mask position t only sees
+    ids[:, :t+1]; src/models/trocr_model.py:274-287).  This is the golden for the product's KV-cached ``generate`` --
+    HF ``generate`` under transformers 5.x is not usable as one.  Finished rows (EOS emitted) are padded.
+    Returns (ids [B, max_length] int64, top-2 logit gap of every decision [B, steps])."""
+    px = torch.as_tensor(pixel_values)
+    B = px.shape[0]
+    with torch.no_grad():
+        enc = encoder_forward(cfg, sd, px)
+        if cfg.has_proj:
+            enc = F.linear(enc, sd["encoder_decoder_proj.weight"], sd["encoder_decoder_proj.bias"])
+        ids = torch.full((B, max_length), cfg.pad_id, dtype=torch.int64)
+        ids[:, 0] = cfg.bos_id
+        done = torch.zeros(B, dtype=torch.bool)
+        gaps = []
+        for t in range(max_length - 1):
+            lg = decoder_forward(cfg, sd, ids[:, :-1], enc)[:, t]
+            top2 = lg.topk(2, dim=-1).values
+            gaps.append((top2[:, 0] - top2[:, 1]).masked_fill(done, float("inf")))
+            nxt = lg.argmax(-1)
+            nxt = torch.where(done, torch.full_like(nxt, cfg.pad_id), nxt)
+            ids[:, t + 1] = nxt
+            done |= nxt == cfg.eos_id
+            if bool(done.all()):
+                break
+    return ids.numpy(), torch.stack(gaps, 1).numpy()
+
+
+def stepwise_logits(cfg, sd, pixel_values, repeat=1):
+    """Closure ``step(t, ids) -> logits [B*repeat, V]`` of position t given ids[:, :t+1], through the training-branch
+    decoder over the prefix (encoder run once; rows repeated ``repeat`` times for beam search).  Drives kzv/beam.py's
+    token selection with ORACLE logits, which is the golden of the engine's ``forward(labels=None)`` (beam 4)."""
+    with torch.no_grad():
+        enc = encoder_forward(cfg, sd, torch.as_tensor(pixel_values))
+        if cfg.has_proj:
+            enc = F.linear(enc, sd["encoder_decoder_proj.weight"], sd["encoder_decoder_proj.bias"])
+        enc = enc.repeat_interleave(repeat, dim=0)
+
+    def step(t, ids):
+        with torch.no_grad():
+            return decoder_forward(cfg, sd, ids[:, :t + 1].contiguous(), enc)[:, t]
+    return step

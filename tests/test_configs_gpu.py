@@ -1,0 +1,190 @@
+"""BASELINE.json configs and the data-parallel code path on the GPU:
+  * configs[0] at its stated geometry (384 / 6 layers / 6 heads encoder on 64x640 crops, 32 synthetic crops) through the CLI
+    and against the oracle;
+  * configs[1] at FULL size (ViT-B/16 + 6-layer decoder, batch 256) through size-independent properties;
+  * the real Stepper with two ranks sharing the one GPU over gloo against a single process that averages the two ranks'
+    gradients by hand (mean of rank means, clip AFTER the reduce: scripts/train_trocr.py:166-176);
+  * the kernel selections data-parallel mode switches on (kzv_set_cu_reserve(32)) and KZV_SIDE_STREAM=1, re-running the
+    reference-fixture parity and the large GEMM shapes under them.
+"""
+import dataclasses
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from kzv import params as P
+from kzv.config import small_config, tiny_config, vit_b_config
+from kzv.data import build_decoder_dir, synthetic_batch
+from kzv.model import TrOCRModel
+from oracle import trocr_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_dropout(cfg):
+    return dataclasses.replace(cfg, enc_hidden_dropout=0.0, enc_attn_dropout=0.0, dec_hidden_dropout=0.0, dec_attn_dropout=0.0)
+
+
+def _make(cfg, tmp_path, seed=42, **kw):
+    d = build_decoder_dir(str(tmp_path / f"dec{cfg.vocab}_{cfg.enc_hidden}"), cfg)
+    return TrOCRModel(cfg.encoder_config_dict(), d, init_seed=seed, load_tokenizer=False, **kw)
+
+
+# ----------------------------------------------------------------------------------------------- configs[0]
+def test_config0_small_geometry_matches_oracle(tmp_path):
+    cfg = _no_dropout(small_config())
+    m = _make(cfg, tmp_path, 3)
+    px, lab = synthetic_batch(cfg, 2, 32, seed=6, min_chars=4, max_chars=30)
+    m.train()
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    m.backward()
+    torch.cuda.synchronize()
+    r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 3)), px, lab)
+    assert np.abs(out["logits"].cpu().numpy() - r["logits"]).max() < 3e-2
+    assert abs(float(out["loss"]) - r["loss"]) < 5e-3
+    g = m.grad_dict()
+    for k, v in r["grads"].items():
+        if v is None or k.endswith("key.bias"):
+            continue
+        got = g[k].cpu().numpy().reshape(v.shape)
+        assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, k
+
+
+def test_config0_cli_32_synthetic_crops(tmp_path):
+    """`ocr_lightning/train.py`-style run of configs[0]: TrOCR-small, 32 synthetic 64x640 crops, one-char tokenizer."""
+    from kzv.train import main
+    hist = main(["--synthetic", "32", "--batch_size", "8", "--image_size", "64", "640", "--encoder_hidden_size", "384",
+                 "--encoder_num_layers", "6", "--encoder_num_heads", "6", "--max_epochs", "1", "--max_length", "32",
+                 "--output_dir", str(tmp_path), "--experiment_name", "small"])
+    assert hist and all(np.isfinite(v) for _, v in hist)
+    names = sorted(p.name for p in (tmp_path / "small" / "checkpoints").iterdir())
+    assert "last.ckpt" in names
+
+
+# ----------------------------------------------------------------------------------------------- configs[1], full size
+def test_config1_full_batch_256_properties(tmp_path):
+    """The bench shape under a test: finite loss near ln(V); trimmed == untrimmed decoder; two same-seed steps (dropout
+    ON) agree to float-atomic order; a different seed does not."""
+    cfg = vit_b_config(dec_layers=6)
+    m = _make(cfg, tmp_path, 42)
+    px, lab = synthetic_batch(cfg, 256, 128, seed=1)
+    pxt, labt = torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()
+    m.train()
+    res = []
+    for trim, seed in ((True, 11), (True, 11), (False, 11), (True, 12)):
+        m.trim_padding = trim
+        loss, _ = m.forward_loss(pxt, labt, seed=seed)
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.item()), m.flat_grads.clone()))
+    assert all(np.isfinite(r[0]) for r in res) and abs(res[0][0] - np.log(cfg.vocab)) < 0.5
+    assert m.last_active_length == int((lab != cfg.pad_id).sum(1).max())
+    gmax = res[0][1].abs().max().item()
+    assert torch.isfinite(res[0][1]).all() and gmax > 0
+    assert abs(res[0][0] - res[1][0]) < 1e-5 and (res[0][1] - res[1][1]).abs().max().item() < 1e-3 * gmax      # same seed
+    assert abs(res[0][0] - res[2][0]) < 1e-4 and (res[0][1] - res[2][1]).abs().max().item() < 1e-3 * gmax      # trim is exact
+    assert (res[0][1] - res[3][1]).abs().max().item() > 1e-2 * gmax                                            # another mask
+    # gradient norm per tensor against a B=2 oracle is covered by the fixture tests; here: every tensor received a gradient
+    for k, v in m.grad_dict().items():
+        if not k.endswith("key.bias") and "token_type" not in k:
+            assert v.abs().max().item() > 0, k
+
+
+# ----------------------------------------------------------------------------------------------- DP on one GPU
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_stepper_on_one_gpu(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _stepper_worker as W
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   KZV_DIST_BACKEND="gloo", KZV_FORCE_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_stepper_worker.py"), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert torch.equal(r0["params"], r1["params"])            # identical gradients after the reduce -> identical replicas
+    assert r0["norms"] == r1["norms"]                         # the clip saw the same (reduced) gradient on both ranks
+    # single process: per-rank gradients averaged by hand, then clip + step on the averaged gradient
+    cfg = W.run_config()
+    m = _make(cfg, tmp_path, 4, learning_rate=W.LR)
+    opt = m.configure_optimizers()
+    m.train()
+    for step in range(W.STEPS):
+        acc = torch.zeros_like(m.flat_grads)
+        for rank in range(2):
+            b = W.shard_batch(cfg, step, rank, 2, W.PER_RANK)
+            m.forward_loss(b["pixel_values"], b["labels"])
+            m.backward()
+            acc += m.flat_grads
+        m.flat_grads.copy_(acc / 2)
+        opt.step(max_grad_norm=1.0, grad_scale=1.0)
+        assert abs(opt.grad_norm() - r0["norms"][step]) < 1e-4 * r0["norms"][step] + 1e-9
+    torch.cuda.synchronize()
+    mine, theirs = P.state_dict_from_flat(cfg, m.flat_params.cpu().numpy()), P.state_dict_from_flat(cfg, r0["params"].numpy())
+    init = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 4))
+    moved = 0.0
+    for k in mine:
+        if k.endswith("key.bias"):      # exactly-zero true gradient: Adam normalises float-atomic noise there
+            continue
+        scale = np.abs(mine[k]).max() + 1e-12
+        assert np.abs(mine[k] - theirs[k]).max() < 2e-5 * scale + 1e-7, k
+        moved = max(moved, float(np.abs(mine[k] - init[k].reshape(mine[k].shape)).max()))
+    assert moved > 1e-3                   # the steps after the optimizer's silent phase moved the parameters
+
+
+# ----------------------------------------------------------------------------------------------- DP kernel selections
+@pytest.mark.parametrize("env", [{"KZV_CU_RESERVE": "32"}, {"KZV_SIDE_STREAM": "1"}, {"KZV_CU_RESERVE": "32", "KZV_SIDE_STREAM": "1"}])
+def test_parity_under_dp_kernel_selection_and_side_stream(env):
+    """kzv_set_cu_reserve(32) (kzv/trainer.py sets it when world_size > 1: gemm_nt drops the persistent kernel, gemm_tn256
+    resizes its token splits) and KZV_SIDE_STREAM=1 (weight gradients on a side stream, buffer reuse guarded by events):
+    the reference-fixture parity tests and the large GEMM shapes in a child process under those settings."""
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_model_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_ops_gpu.py"), os.path.join(ROOT, "tests", "test_parity_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "tiny_matches_reference_fixture or vitb_summary_matches_reference_fixture or large_shapes or large_outputs "
+                              "or mask_replay_vit_b or trailing_padding", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_cu_reserve_changes_the_launch_plan():
+    """the child-process test above is only meaningful if the knob is read: with a reserve the persistent kernel must not
+    be chosen (observable through the profiling hook's launch count staying equal while results stay equal is not enough),
+    so check the setter round-trips and rejects nonsense."""
+    from kzv import _lib as L
+    lib = L.load()
+    assert lib.kzv_set_cu_reserve(32) == 0
+    assert lib.kzv_set_cu_reserve(0) == 0
+    assert lib.kzv_set_cu_reserve(-1) != 0 and lib.kzv_set_cu_reserve(10_000) != 0
+
+
+def test_generate_at_the_reference_default_geometry_1024x64(tmp_path):
+    """1024x64 columns give 256 cross-attention keys; the KV-cached step must take them (it refused
+    more than 192) -- greedy and beam-4, cached against the prefix-recompute form."""
+    cfg = dataclasses.replace(_no_dropout(tiny_config()), image_h=1024, image_w=64)
+    m = _make(cfg, tmp_path, 11)
+    m.eval()
+    px, _ = synthetic_batch(cfg, 3, 12, seed=4)
+    pxt = torch.from_numpy(px)
+    for beams in (1, 4):
+        g1 = m.generate(pxt, max_length=10, num_beams=beams, early_stopping=False, use_cache=True).cpu()
+        g0 = m.generate(pxt, max_length=10, num_beams=beams, early_stopping=False, use_cache=False).cpu()
+        w = min(g0.shape[1], g1.shape[1])
+        assert float((g0[:, :w] == g1[:, :w]).float().mean()) > 0.9       # untrained, nearly flat logits: rare ties may flip
+    out = m(pxt)                     # the inference branch as validation_step calls it (beam 4, max_length 128)
+    assert out["generated_ids"].shape[0] == 3

@@ -179,3 +179,61 @@ def test_ddp_mean_of_rank_means_two_ranks_gloo(tmp_path):
     ref = np.load(tmp_path / "ref.npy")
     assert np.array_equal(a, b)
     np.testing.assert_allclose(a, ref, atol=2e-6, rtol=1e-4)
+
+
+def test_beam_and_greedy_bookkeeping_equal_hf_generate():
+    """kzv/beam.py against transformers' own ``generate`` (the call the reference makes at trocr_model.py:306-316) on a
+    small RobertaForCausalLM(is_decoder, add_cross_attention): same step logits -> the token-selection bookkeeping must
+    return identical sequences for greedy and for beam search (early_stopping True/False, length penalties, max_length
+    cut-offs, EOS-heavy and EOS-free models).  The step function feeds HF's forward with the position ids 5.x ``generate``
+    itself supplies (0-based arange -- SURVEY.md H13; that is why HF ``generate`` is no golden for the ENGINE's logits),
+    which is checked first through the greedy comparison."""
+    import warnings
+
+    import torch
+    from transformers import RobertaConfig, RobertaForCausalLM
+
+    from kzv import beam as BM
+    warnings.filterwarnings("ignore")
+    V, B, H = 13, 4, 32
+    cfg = RobertaConfig(vocab_size=V, hidden_size=H, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+                        max_position_embeddings=40, pad_token_id=1, bos_token_id=2, eos_token_id=3, is_decoder=True,
+                        add_cross_attention=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    n_eos_endings = 0
+    for seed, eos_bias in ((0, 0.0), (1, 2.5), (2, 4.0)):
+        torch.manual_seed(seed)
+        m = RobertaForCausalLM(cfg).eval()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.mul_(3.0)                      # less flat logits
+            m.lm_head.bias[3] += eos_bias        # how often EOS shows up among the candidates
+        enc = torch.randn(B, 6, H) * 8
+
+        def run_hf(nb, L, es, lp):
+            with torch.no_grad():
+                return m.generate(torch.full((B, 1), 2, dtype=torch.long), encoder_hidden_states=enc, max_length=L, num_beams=nb,
+                                  early_stopping=es, length_penalty=lp, pad_token_id=1, eos_token_id=3, use_cache=False,
+                                  do_sample=False, return_dict_in_generate=True).sequences
+
+        def make_step(nb):
+            e = enc.repeat_interleave(nb, 0)
+
+            def step(t, ids):
+                x = ids[:, :t + 1]
+                with torch.no_grad():
+                    return m(input_ids=x, encoder_hidden_states=e, attention_mask=torch.ones_like(x),
+                             position_ids=torch.arange(t + 1)[None].expand_as(x)).logits[:, -1]
+            return step
+
+        g, h = BM.greedy(make_step(1), B, 12, 1, 2, 3, "cpu"), run_hf(1, 12, False, 1.0)
+        assert g.shape == h.shape and torch.equal(g, h)
+        for nb, L, es, lp in ((4, 16, True, 1.0), (4, 16, False, 1.0), (3, 7, True, 1.0), (2, 12, False, 2.0), (4, 12, True, 0.0)):
+            h = run_hf(nb, L, es, lp)
+            rows_seen = []
+            g = BM.beam_search(make_step(nb), lambda rows, t: rows_seen.append((t, rows.clone())), B, nb, L, V, 1, 2, 3, "cpu",
+                               early_stopping=es, length_penalty=lp)
+            assert g.shape == h.shape and torch.equal(g, h), (seed, nb, L, es, lp, g, h)
+            n_eos_endings += int((h == 3).any(dim=1).sum())
+            for t, rows in rows_seen:               # cache rows: every row continues from a row of its own batch element
+                assert rows.shape == (B * nb,) and torch.equal(rows // nb, torch.arange(B).repeat_interleave(nb))
+    assert n_eos_endings > 10                        # the EOS / finished-hypothesis paths were exercised

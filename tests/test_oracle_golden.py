@@ -85,3 +85,71 @@ def test_cer_kat(golden_dir):
     # tests/test_ocr_model.py:129-147 of the reference: corpus CER 2/9 for these pairs
     preds, tgts = ["ac", "cot", "test"], ["ab", "cat", "test"]
     assert sum(O.levenshtein(p, t) for p, t in zip(preds, tgts)) / sum(map(len, tgts)) == pytest.approx(2 / 9)
+
+
+def test_cer_independent_known_answers(golden_dir):
+    """Edit distances a reader can check by hand, and the CER values the REFERENCE's calculate_cer returned for them
+    with a Wagner-Fischer matrix bound as ``editdistance`` (tools/gen_golden_trained.py: a different algorithm from the
+    two-row scans of the oracle and of kzv/model.py, itself checked against the recursive definition)."""
+    from kzv.model import _levenshtein
+    hand = {("kitten", "sitting"): 3, ("flaw", "lawn"): 2, ("intention", "execution"): 5, ("sunday", "saturday"): 3,
+            ("ac", "ab"): 1, ("cot", "cat"): 1, ("test", "test"): 0, ("", "abc"): 3, ("abc", ""): 3, ("", ""): 0}
+    for (a, b), d in hand.items():
+        assert O.levenshtein(a, b) == d and _levenshtein(a, b) == d and O.levenshtein(b, a) == d
+    g = _load(golden_dir, "tiny_trained.npz")
+    for p, t, c in zip(g["cer/preds"], g["cer/targets"], g["cer/values"]):
+        assert O.calculate_cer(str(p), str(t)) == float(c)
+    rng = np.random.default_rng(3)
+    import functools
+
+    def rec(a, b):
+        @functools.lru_cache(maxsize=None)
+        def f(i, j):
+            if i == 0 or j == 0:
+                return i + j
+            return min(f(i - 1, j) + 1, f(i, j - 1) + 1, f(i - 1, j - 1) + (a[i - 1] != b[j - 1]))
+        return f(len(a), len(b))
+    for _ in range(200):
+        a = "".join(rng.choice(list("abc"), rng.integers(0, 8)))
+        b = "".join(rng.choice(list("abc"), rng.integers(0, 8)))
+        assert O.levenshtein(a, b) == rec(a, b) == _levenshtein(a, b)
+
+
+def test_oracle_reproduces_the_trained_reference(golden_dir):
+    """tiny_trained.npz: peaked logits.  The oracle must give the reference's logits, EVERY argmax, the same step-wise
+    greedy tokens and (through the repo's tokenizer directory) the same strings and CER."""
+    from _trained import load, pad_to
+    g, cfg, sd, data = load()
+    tsd = O.leaf_state_dict(sd, requires_grad=False)
+    for tag, (px, lab) in data.items():
+        logits, loss = O.forward(cfg, tsd, torch.from_numpy(px), torch.from_numpy(lab))
+        np.testing.assert_allclose(logits.numpy(), g[f"{tag}/logits"], atol=5e-5, rtol=0)
+        assert abs(float(loss) - float(g[f"{tag}/loss"])) < 2e-5
+        assert np.array_equal(logits.numpy().argmax(-1), g[f"{tag}/argmax"])
+        ids, gaps = O.greedy_stepwise(cfg, tsd, px, int(g["label_len"]))
+        assert np.array_equal(ids, g[f"{tag}/greedy_ids"])
+    assert float(g["fit/top2_gap"][data["fit"][1][:, 1:] != cfg.pad_id].min()) > 5.0      # peaked where it was fitted
+
+
+def test_oracle_explicit_dropout_masks():
+    """oracle masks plumbing: all-ones masks == eval mode; a mask drawn like nn.Dropout reproduces F.dropout's arithmetic."""
+    cfg = tiny_config()
+    px, lab = synthetic_batch(cfg, 2, 10, seed=3, min_chars=2, max_chars=9)
+    sd = O.leaf_state_dict(P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 1)), requires_grad=False)
+    base, _ = O.forward(cfg, sd, torch.from_numpy(px), torch.from_numpy(lab))
+    B, T, Se = 2, 9, cfg.enc_seq
+    shapes = {"enc_emb": (B, Se, cfg.enc_hidden), "dec_emb": (B, T, cfg.dec_hidden)}
+    for i in range(cfg.enc_layers):
+        shapes[f"enc{i}_attn"] = (B, cfg.enc_heads, Se, Se)
+        shapes[f"enc{i}_o"] = shapes[f"enc{i}_mlp"] = (B, Se, cfg.enc_hidden)
+    for i in range(cfg.dec_layers):
+        shapes[f"dec{i}_sa"] = (B, cfg.dec_heads, T, T)
+        shapes[f"dec{i}_ca"] = (B, cfg.dec_heads, T, cfg.num_patches)
+        shapes[f"dec{i}_sa_o"] = shapes[f"dec{i}_ca_o"] = shapes[f"dec{i}_ffn"] = (B, T, cfg.dec_hidden)
+    ones, _ = O.forward(cfg, sd, torch.from_numpy(px), torch.from_numpy(lab), masks={k: torch.ones(s) for k, s in shapes.items()})
+    assert torch.equal(ones, base)
+    gen = torch.Generator().manual_seed(0)
+    for name, shp in shapes.items():
+        mk = (torch.rand(shp, generator=gen) >= 0.5).float() * 2.0
+        out, _ = O.forward(cfg, sd, torch.from_numpy(px), torch.from_numpy(lab), masks={name: mk})
+        assert float((out - base).abs().max()) > 1e-6, name      # every site is wired
