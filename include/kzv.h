@@ -75,6 +75,13 @@ int kzv_model_sync_weights(kzv_model* m, void* stream);
 int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels,
                      float* d_loss, float* d_logits, int train, uint64_t seed, void* stream);
 
+/* Position-id overflow check of the LAST kzv_forward_loss / kzv_decode_logits on this handle: RoBERTa's position ids
+ * (count of non-pad decoder inputs + pad_id, HF modeling_roberta.py:142-155) must index the [max_pos, H] table; the reference
+ * raises "index out of range" for longer labels, the kernels clamp and raise a device flag.  Synchronises `stream`, reads the
+ * flag (cleared by every forward) and returns KZV_E_ARG when it was set.  Optional: the Python host validates labels it can
+ * see on the CPU before the call. */
+int kzv_check_positions(kzv_model* m, void* stream);
+
 /* Active decoder length.  Labels are [B, L] rows padded to L; when every sample's characters end before column
  * t_active + 1, decoder positions >= t_active hold only padding: they are masked as attention keys, their targets are
  * ignored by the loss and nothing reads their outputs, so the engine may run the decoder on the packed [B, t_active]

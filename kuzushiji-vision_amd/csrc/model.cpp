@@ -656,6 +656,16 @@ extern "C" int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const
     return rc;
 }
 
+extern "C" int kzv_check_positions(kzv_model* m, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "check_positions: model not bound");
+    int flag = 0;
+    if (hipMemcpyAsync(&flag, m->err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return kzv_fail(KZV_E_HIP, "check_positions: copy");
+    if (flag) return kzv_fail(KZV_E_ARG, "labels too long: a position id reached max_position_embeddings = %d (index out of range in the reference)", m->c.max_pos);
+    return KZV_OK;
+}
+
 extern "C" int kzv_set_active_length(kzv_model* m, int t_active) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "set_active_length: model not bound");
     if (t_active < 1 || t_active > m->T) return kzv_fail(KZV_E_ARG, "set_active_length: must be in 1..%d", m->T);

@@ -75,6 +75,7 @@ SYMBOLS = {
     "kzv_model_bind": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int]),
     "kzv_model_sync_weights": (C.c_int, [_P, _P]),
     "kzv_forward_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
+    "kzv_check_positions": (C.c_int, [_P, _P]),
     "kzv_set_active_length": (C.c_int, [_P, C.c_int]),
     "kzv_decode_logits": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "kzv_zero_grads": (C.c_int, [_P, _P]),

@@ -180,3 +180,9 @@ def tiny_config() -> ModelConfig:
     """Test geometry: every op exercised, seconds on a CPU. head_dim stays 64."""
     return ModelConfig(image_h=32, image_w=64, enc_hidden=128, enc_layers=2, enc_heads=2, enc_ffn=256,
                        dec_hidden=64, dec_layers=2, dec_heads=1, dec_ffn=128, vocab=157, max_pos=40)
+
+
+def micro_config() -> ModelConfig:
+    """Smallest geometry the engine accepts (checkpoint fixtures): 16x32 image, 8x8 patches, one layer each."""
+    return ModelConfig(image_h=16, image_w=32, patch_h=8, patch_w=8, enc_hidden=64, enc_layers=1, enc_heads=1, enc_ffn=64,
+                       dec_hidden=64, dec_layers=1, dec_heads=1, dec_ffn=64, vocab=37, max_pos=16)

@@ -122,12 +122,29 @@ def image_to_tensor(image):
     return torch.from_numpy(((a - 0.5) / 0.5).transpose(2, 0, 1).copy())
 
 
+def reference_image_path(column_image: str) -> str:
+    """``create_full_path`` of TrOCRDataset._load_data (src/data/trocr_dataset.py:121-130): absolute paths as they are,
+    ``processed_v2/...`` rewritten to ``data/processed_v2/...``, anything else relative to the working directory.
+    (The reference stores ``image_root`` but never uses it.)"""
+    if column_image.startswith("/"):
+        return column_image
+    if column_image.startswith("processed_v2/"):
+        return column_image.replace("processed_v2/", "data/processed_v2/", 1)
+    return os.path.join(os.getcwd(), column_image)
+
+
 class LineCsvDataset:
     """TrOCRDataset (src/data/trocr_dataset.py:56-201): column_info.csv rows -> {"pixel_values","labels","text",
-    "image_path"}; deterministic 42-seeded shuffle, then train/val/test slices; unreadable images become zeros."""
+    "image_path"}.  Rows are kept in FILE order (no shuffle); rows with missing fields, empty text or -- like the reference
+    (:132-136) -- a non-existent image file are dropped BEFORE the train/val/test slices are cut, so the split boundaries
+    are the reference's.  Images that exist but cannot be decoded become all-zero tensors (:182-185).
+
+    ``resolve="reference"`` (default) locates images by the reference's rules (reference_image_path);
+    ``resolve="image_root"`` joins ``image_root`` with the file's basename instead (an extension for relocated datasets;
+    the existence filter applies to the resolved path either way)."""
 
     def __init__(self, csv_path, image_root, tokenizer, image_size=(1024, 64), max_length=128, split="train",
-                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, device_preprocess=False):
+                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, device_preprocess=False, resolve="reference"):
         import ast
         import pandas as pd
         if abs(train_ratio + val_ratio + test_ratio - 1.0) >= 1e-6:
@@ -138,6 +155,13 @@ class LineCsvDataset:
         df["unicode_ids"] = df["unicode_ids"].apply(ast.literal_eval)
         df["text"] = df["unicode_ids"].apply(self._ids_to_text)
         df = df[df["text"].str.len() > 0]
+        if resolve == "reference":
+            df["full_image_path"] = df["column_image"].apply(reference_image_path)
+        elif resolve == "image_root":
+            df["full_image_path"] = df["column_image"].apply(lambda r: os.path.join(image_root, os.path.basename(r)))
+        else:
+            raise ValueError(f"Invalid resolve: {resolve}")
+        df = df[df["full_image_path"].apply(os.path.exists)]      # trocr_dataset.py:135
         df = df.reset_index(drop=True)          # the reference slices in file order (trocr_dataset.py:153-171)
         n = len(df)
         a, b = int(n * train_ratio), int(n * (train_ratio + val_ratio))
@@ -168,8 +192,7 @@ class LineCsvDataset:
         import torch
         from PIL import Image
         row = self.data.iloc[idx]
-        rel = row["column_image"]
-        path = rel if rel.startswith(self.image_root) else os.path.join(self.image_root, os.path.basename(rel))
+        path = row["full_image_path"]
         enc = self.tokenizer(row["text"], max_length=self.max_length, padding="max_length", truncation=True,
                              return_tensors="pt")
         item = {"labels": enc["input_ids"].squeeze(0), "text": row["text"], "image_path": path}
@@ -231,23 +254,48 @@ class DeviceBatchLoader:
     def __len__(self):
         return len(self.loader)
 
+    def set_epoch(self, epoch):
+        self.loader.set_epoch(epoch)
+
     def __iter__(self):
         for b in self.loader:
             yield device_batch(b, self.preprocessor)
 
 
+class EpochSampler:
+    """Index stream of one rank: ``DataLoader(shuffle=True)`` reshuffles every epoch (src/data/trocr_dataset.py:256-262)
+    and Lightning wraps it in a DistributedSampler (seed + epoch permutation, padded to a multiple of the world size,
+    rank r takes indices r, r + world, ...; ``set_epoch`` is called by the fit loop)."""
+
+    def __init__(self, n: int, shuffle: bool, seed: int = 42, rank: int = 0, world: int = 1):
+        self.n, self.shuffle, self.seed, self.rank, self.world, self.epoch = n, shuffle, seed, rank, world, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        return (self.n + self.world - 1) // self.world
+
+    def __iter__(self):
+        import torch
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        total = len(self) * self.world
+        if total > len(idx) and idx:
+            idx = idx + (idx * ((total - len(idx)) // len(idx) + 1))[: total - len(idx)]
+        return iter(idx[self.rank:total:self.world])
+
+
 def make_loader(dataset, batch_size, shuffle, seed=42, rank=0, world=1, drop_last=False, num_workers=0, preprocessor=None):
-    """DataLoader with a DistributedSampler-style shard (every rank sees len/world samples of the same permutation).
-    `preprocessor` (kzv.preprocess.DevicePreprocessor): for datasets built with device_preprocess=True."""
-    import torch
-    from torch.utils.data import DataLoader, Subset
-    idx = list(range(len(dataset)))
-    if shuffle:
-        g = torch.Generator().manual_seed(seed)
-        idx = torch.randperm(len(dataset), generator=g).tolist()
-    if world > 1:
-        per = (len(idx) + world - 1) // world
-        idx = (idx + idx[: per * world - len(idx)])[rank::world]
-    loader = DataLoader(Subset(dataset, idx), batch_size=batch_size, shuffle=False, collate_fn=collate, drop_last=drop_last,
+    """DataLoader over an EpochSampler (per-epoch reshuffle, DistributedSampler-style shard).  drop_last defaults to
+    False like the reference's loaders.  `preprocessor` (kzv.preprocess.DevicePreprocessor): for datasets built with
+    device_preprocess=True.  The returned loader exposes ``set_epoch``."""
+    from torch.utils.data import DataLoader
+    sampler = EpochSampler(len(dataset), shuffle, seed, rank, world)
+    loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate, drop_last=drop_last,
                         num_workers=num_workers)
+    loader.set_epoch = sampler.set_epoch
     return DeviceBatchLoader(loader, preprocessor) if preprocessor is not None else loader

@@ -199,6 +199,12 @@ class TrOCRModel:
         n_max_host = None
         if labels.device.type == "cpu" and labels.dim() == 2:      # dataloader batches: length known without touching the GPU
             n_max_host = int((labels != self.cfg.pad_id).sum(dim=1).max())
+            # RoBERTa position ids run to (non-pad decoder inputs) + pad_id and index a [max_pos, H] table
+            # (HF modeling_roberta.py:142-155): a longer label raises in the reference ("index out of range in self")
+            n_in = int((labels[:, :-1] != self.cfg.pad_id).sum(dim=1).max()) if labels.shape[1] > 1 else 0
+            if n_in + self.cfg.pad_id >= self.cfg.max_pos:
+                raise IndexError(f"index out of range in self: {n_in} decoder input tokens need position id {n_in + self.cfg.pad_id}, "
+                                 f"the position table has {self.cfg.max_pos} rows")
         lab = labels.to(self.device, dtype=torch.int64).contiguous()
         if lab.dim() != 2 or lab.shape[0] != px.shape[0]:
             raise ValueError("labels must be [B, L]")

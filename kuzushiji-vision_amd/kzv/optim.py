@@ -64,6 +64,7 @@ class RAdamScheduleFree:
         lib = L.load()
         m = self.model
         lr, ckp1, bc2, adaptive = self._next_scalars()
+        self._last_scale = abs(grad_scale)
         st = L.stream_handle()
         n = m.flat_params.numel()
         if max_grad_norm > 0:
@@ -76,8 +77,8 @@ class RAdamScheduleFree:
         m.sync_weights()
 
     def grad_norm(self) -> float:
-        """Total L2 norm of the last step's (unscaled) gradients."""
-        return float(self._sq.sqrt().item())
+        """Total L2 norm of the gradient the last step clipped, i.e. AFTER the data-parallel mean (grad_scale applied)."""
+        return float(self._sq.sqrt().item()) * getattr(self, "_last_scale", 1.0)
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_grad()
@@ -99,13 +100,15 @@ class RAdamScheduleFree:
             self.train_mode = True
 
     def state_dict(self):
+        """Flat-buffer form of schedulefree's state (kzv/checkpoint.py turns it into the per-parameter layout)."""
         return {"k": self.k, "lr_max": self.lr_max, "weight_sum": self.weight_sum, "train_mode": self.train_mode,
-                "z": self.z.detach().cpu(), "v": self.v.detach().cpu(),
-                "hparams": {"lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps,
-                            "weight_decay": self.weight_decay}}
+                "scheduled_lr": self.scheduled_lr, "z": self.z.detach().cpu(), "v": self.v.detach().cpu(),
+                "lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": self.weight_decay,
+                "r": self.r, "weight_lr_power": self.weight_lr_power, "silent_sgd_phase": self.silent_sgd_phase}
 
     def load_state_dict(self, sd):
-        self.k, self.lr_max, self.weight_sum = sd["k"], sd["lr_max"], sd["weight_sum"]
-        self.train_mode = sd["train_mode"]
+        self.k, self.lr_max, self.weight_sum = int(sd["k"]), float(sd["lr_max"]), float(sd["weight_sum"])
+        self.scheduled_lr = float(sd.get("scheduled_lr", 0.0))
+        self.train_mode = bool(sd["train_mode"])
         self.z.copy_(sd["z"])
         self.v.copy_(sd["v"])

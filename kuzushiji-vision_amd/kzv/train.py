@@ -29,7 +29,9 @@ def parse_args(argv=None):
     p.add_argument("--patch_size", type=int, nargs=2, default=[16, 16])
     p.add_argument("--encoder_hidden_size", type=int, default=768)
     p.add_argument("--encoder_num_layers", type=int, default=12)
-    p.add_argument("--encoder_num_heads", type=int, default=8)
+    p.add_argument("--encoder_num_heads", type=int, default=12,
+                   help="the reference defaults to 8 (head_dim 96, scripts/train_trocr.py:43); this engine's attention kernels are built "
+                        "for head_dim 64, so the default here is hidden_size / 64 = 12 (ViT-B/16)")
     p.add_argument("--max_length", type=int, default=128)
     # training (:47-54)
     p.add_argument("--batch_size", type=int, default=64)
@@ -55,6 +57,7 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--device_preprocess", action="store_true",
                    help="resize / pad / normalise the decoded crops on the GPU (kzv.preprocess; byte-exact with the PIL transform)")
+    p.add_argument("--skip_test", action="store_true", help="do not run the reference's post-fit test phase (scripts/train_trocr.py:193-195)")
     p.add_argument("--ema_decay", type=float, default=0.0, help="> 0 attaches kzv.ema.EMACallback (reference: decay 0.9999)")
     return p.parse_args(argv)
 
@@ -65,7 +68,7 @@ def main(argv=None):
     from .config import ModelConfig
     from .data import LineCsvDataset, SyntheticLineDataset, build_decoder_dir, make_loader
     from .model import TrOCRModel
-    from .trainer import fit, init_distributed
+    from .trainer import fit, init_distributed, test as run_test
 
     if args.devices is not None:
         args.gpus = int(args.devices) if str(args.devices).isdigit() else len(str(args.devices).split(","))
@@ -74,7 +77,9 @@ def main(argv=None):
     if args.precision != "bf16-mixed":
         raise SystemExit("the engine implements bf16-mixed (scripts/train_trocr.py:68 default) only")
     if args.encoder_hidden_size != 64 * args.encoder_num_heads:
-        raise SystemExit("head_dim must be 64: --encoder_hidden_size must equal 64 * --encoder_num_heads")
+        raise SystemExit(f"head_dim {args.encoder_hidden_size / max(1, args.encoder_num_heads):g} is not supported: the attention kernels are built "
+                         "for head_dim 64, so --encoder_hidden_size must equal 64 * --encoder_num_heads (the reference's own default, 768 / 8 heads = "
+                         "head_dim 96, is NOT available; use --encoder_num_heads 12)")
     rank, world, local = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU with torch.distributed.run")
@@ -101,20 +106,22 @@ def main(argv=None):
         n_val = max(args.batch_size, args.synthetic // 10)
         train_ds = SyntheticLineDataset(model.cfg, args.synthetic, args.max_length, seed=args.seed)
         val_ds = SyntheticLineDataset(model.cfg, n_val, args.max_length, seed=args.seed + 1)
+        test_ds = SyntheticLineDataset(model.cfg, n_val, args.max_length, seed=args.seed + 2)
     else:
         kw = dict(csv_path=args.csv_path, image_root=args.image_root, tokenizer=model.tokenizer, image_size=tuple(args.image_size),
                   max_length=args.max_length, train_ratio=args.train_ratio, val_ratio=args.val_ratio, test_ratio=args.test_ratio)
         kw["device_preprocess"] = args.device_preprocess
-        train_ds, val_ds = LineCsvDataset(split="train", **kw), LineCsvDataset(split="val", **kw)
+        train_ds, val_ds, test_ds = LineCsvDataset(split="train", **kw), LineCsvDataset(split="val", **kw), LineCsvDataset(split="test", **kw)
     pre = None
     if args.device_preprocess and not args.synthetic:
         from .preprocess import DevicePreprocessor
         pre = DevicePreprocessor(tuple(args.image_size), device=f"cuda:{local}")
     nw = 0 if args.synthetic else max(0, args.num_workers)      # decode (and, without --device_preprocess, resize) in worker processes
-    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, drop_last=True, num_workers=nw, preprocessor=pre)
+    train_loader = make_loader(train_ds, args.batch_size, True, args.seed, rank, world, num_workers=nw, preprocessor=pre)
     val_loader = make_loader(val_ds, args.batch_size, False, args.seed, rank, world, num_workers=nw, preprocessor=pre)
+    test_loader = make_loader(test_ds, args.batch_size, False, args.seed, rank, world, num_workers=nw, preprocessor=pre)   # scripts/train_trocr.py:93
     if rank == 0:
-        print(f"Train samples: {len(train_ds)}\nVal samples: {len(val_ds)}\nParameters: {model.num_parameters():,}")
+        print(f"Train samples: {len(train_ds)}\nVal samples: {len(val_ds)}\nTest samples: {len(test_ds)}\nParameters: {model.num_parameters():,}")
     cbs = []
     if args.ema_decay > 0:
         from .ema import EMACallback
@@ -124,6 +131,17 @@ def main(argv=None):
                callbacks=cbs)
     if rank == 0:
         print(f"Training completed! Checkpoints saved to: {os.path.join(out_dir, 'checkpoints')}")
+    # scripts/train_trocr.py:193-195: if test_loader is not None: trainer.test(model, test_loader, ckpt_path="best")
+    main.test_metrics = None
+    if not args.skip_test and len(test_ds) > 0:
+        if world > 1:
+            torch.distributed.barrier()            # rank 0 has written the checkpoint the others load
+        path = fit.best_model_path if rank == 0 else None
+        if world > 1:
+            box = [path]
+            torch.distributed.broadcast_object_list(box, src=0)
+            path = box[0]
+        main.test_metrics = run_test(model, test_loader, ckpt_path=path, rank=rank)
     if world > 1:
         torch.distributed.destroy_process_group()
     if tmp is not None:

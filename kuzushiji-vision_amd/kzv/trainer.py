@@ -126,9 +126,12 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
     gstep = 0
     history = []
     best, save_top_k = [], 3          # (val_loss, path) of the kept checkpoints
+    fit.best_model_path = None
     n_batches = len(train_loader)
     val_every = max(1, int(n_batches * val_check_interval)) if val_loader is not None else 0
     for epoch in range(max_epochs):
+        if hasattr(train_loader, "set_epoch"):
+            train_loader.set_epoch(epoch)          # DataLoader(shuffle=True) / DistributedSampler.set_epoch: a new order per epoch
         model.train()
         model.on_train_epoch_start()
         t0 = time.time()
@@ -169,6 +172,7 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
                                 if os.path.exists(stale):
                                     os.remove(stale)
                             del best[save_top_k:]
+                            fit.best_model_path = best[0][1]
             if 0 < max_steps <= gstep:
                 break
         torch.cuda.synchronize()
@@ -179,23 +183,52 @@ def fit(model, train_loader, val_loader=None, max_epochs: int = 1, max_steps: in
     if ckpt_dir and rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
         save_checkpoint(model, opt, os.path.join(ckpt_dir, "last.ckpt"), max_epochs - 1, gstep, callbacks)
+        if fit.best_model_path is None:            # no validation ran: "best" falls back to the last weights, like Lightning
+            fit.best_model_path = os.path.join(ckpt_dir, "last.ckpt")
     return history
 
 
-def save_checkpoint(model, opt, path: str, epoch: int, global_step: int, callbacks=()) -> None:
-    """Lightning-shaped dict: state_dict under HF names + hyper-parameters + optimizer state."""
+def save_checkpoint(model, opt, path: str, epoch: int, global_step: int, callbacks=(), spelling: str = "hf4") -> None:
+    """What Lightning's ModelCheckpoint writes for the reference (scripts/train_trocr.py:136-143): state_dict under HF
+    names in the reference's order, schedulefree's per-parameter optimizer state, hyper_parameters -- kzv/checkpoint.py."""
     import torch
-    ck = {"epoch": epoch, "global_step": global_step, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
-          "hyper_parameters": vars(model.hparams), "optimizer_states": [opt.state_dict()]}
+    from .checkpoint import build_checkpoint
+    ck = build_checkpoint(model.cfg, model.flat_params.detach().cpu(), vars(model.hparams), epoch, global_step,
+                          optimizer=opt.state_dict() if opt is not None else None, spelling=spelling)
     for cb in callbacks:
         ck = cb.on_save_checkpoint(model, ck)
     torch.save(ck, path)
 
 
-def load_checkpoint(model, opt, path: str):
+def load_checkpoint(model, opt, path: str, callbacks=()):
+    """Load a checkpoint written by this engine OR by the reference under Lightning (either ViT key spelling; optimizer
+    state mapped through the checkpoint's own parameter order)."""
     import torch
+    from .checkpoint import read_checkpoint
     ck = torch.load(path, map_location="cpu", weights_only=False)
-    model.load_state_dict(ck["state_dict"], strict=False)
-    if opt is not None and ck.get("optimizer_states"):
-        opt.load_state_dict(ck["optimizer_states"][0])
+    sd, osd = read_checkpoint(ck, model.cfg)
+    model.load_state_dict(sd, strict=True)
+    if opt is not None and osd is not None:
+        opt.load_state_dict(osd)
+    for cb in callbacks:
+        cb.on_load_checkpoint(model, ck)
     return ck
+
+
+def test(model, test_loader, ckpt_path: str | None = None, log=print, rank: int = 0):
+    """``trainer.test(model, test_loader, ckpt_path="best")`` (scripts/train_trocr.py:193-195): load the best checkpoint,
+    switch the optimizer to its eval parameters (on_test_epoch_start, trocr_model.py:441-445), run test_step over the
+    loader, report the epoch means of test_loss / test_cer."""
+    if ckpt_path:
+        load_checkpoint(model, model.optimizers(), ckpt_path)
+    model.eval()
+    model.on_test_epoch_start()
+    model.logged.pop("test_loss", None); model.logged.pop("test_cer", None)
+    for j, b in enumerate(test_loader):
+        model.test_step(b, j)
+    if model.optimizers() is not None:
+        model.optimizers().train()
+    out = {k: (sum(model.logged[k]) / len(model.logged[k]) if model.logged.get(k) else float("nan")) for k in ("test_loss", "test_cer")}
+    if rank == 0:
+        log(f"test_loss {out['test_loss']:.4f} test_cer {out['test_cer']:.4f}")
+    return out

@@ -28,7 +28,7 @@ def run_config():
                                dec_attn_dropout=0.0)
 
 
-STEPS, PER_RANK, LR = 8, 3, 1e-3
+STEPS, PER_RANK, LR, BETA2 = 12, 3, 5e-3, 0.99     # beta2 0.99: RAdam leaves its silent phase at step 6
 
 
 def main():
@@ -36,7 +36,7 @@ def main():
     rank, world, local = init_distributed()
     cfg = run_config()
     d = build_decoder_dir(os.path.join(out, f"dec{rank}"), cfg)
-    m = TrOCRModel(cfg.encoder_config_dict(), d, learning_rate=LR, init_seed=4, load_tokenizer=False, device=f"cuda:{local}")
+    m = TrOCRModel(cfg.encoder_config_dict(), d, learning_rate=LR, beta2=BETA2, init_seed=4, load_tokenizer=False, device=f"cuda:{local}")
     opt = m.configure_optimizers()
     st = Stepper(m, opt, world=world, max_grad_norm=1.0, bucket_mb=0.2)        # several buckets even at tiny size
     assert len(st.buckets) >= 2, st.buckets

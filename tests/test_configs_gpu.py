@@ -67,30 +67,50 @@ def test_config0_cli_32_synthetic_crops(tmp_path):
     assert "last.ckpt" in names
 
 
+def test_cli_with_the_default_model_flags_trains_validates_and_tests(tmp_path):
+    """`python -m kzv.train` with every MODEL flag at its default (1024x64 columns = 257 tokens, ViT-B/16 768/12 layers,
+    max_length 128; ADVICE r01: the defaults must build and run): two steps, the half-epoch validation with beam-4 decoding
+    over 256 cross-attention keys, the checkpoint, and the post-fit test phase on the best checkpoint."""
+    from kzv.train import main, parse_args
+    a = parse_args([])
+    assert a.encoder_hidden_size == 64 * a.encoder_num_heads
+    hist = main(["--synthetic", "8", "--batch_size", "4", "--max_epochs", "1", "--output_dir", str(tmp_path), "--experiment_name", "d"])
+    assert hist and all(np.isfinite(v) for _, v in hist)
+    assert main.test_metrics is not None and np.isfinite(main.test_metrics["test_loss"]) and 0.0 <= main.test_metrics["test_cer"]
+    names = sorted(p.name for p in (tmp_path / "d" / "checkpoints").iterdir())
+    assert "last.ckpt" in names and any(n.startswith("trocr-epoch=00-val_loss=") for n in names)
+
+
 # ----------------------------------------------------------------------------------------------- configs[1], full size
 def test_config1_full_batch_256_properties(tmp_path):
-    """The bench shape under a test: finite loss near ln(V); trimmed == untrimmed decoder; two same-seed steps (dropout
-    ON) agree to float-atomic order; a different seed does not."""
+    """The bench shape under a test: finite loss near ln(V); trimmed == untrimmed decoder (eval mode: dropout masks are
+    indexed by packed token rows, so the two lengths draw different masks in train mode); two same-seed training steps
+    (dropout ON) agree to float-atomic order; a different seed does not."""
     cfg = vit_b_config(dec_layers=6)
     m = _make(cfg, tmp_path, 42)
     px, lab = synthetic_batch(cfg, 256, 128, seed=1)
     pxt, labt = torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()
+    m.eval()
+    ev = []
+    for trim in (True, False):
+        m.trim_padding = trim
+        ev.append(float(m.forward_loss(pxt, labt)[0].item()))
+    assert abs(ev[0] - ev[1]) < 1e-4 and abs(ev[0] - np.log(cfg.vocab)) < 0.5      # fp32 atomic sum over 15-32 k token rows
+    m.trim_padding = True
     m.train()
     res = []
-    for trim, seed in ((True, 11), (True, 11), (False, 11), (True, 12)):
-        m.trim_padding = trim
+    for seed in (11, 11, 12):
         loss, _ = m.forward_loss(pxt, labt, seed=seed)
         m.backward()
         torch.cuda.synchronize()
         res.append((float(loss.item()), m.flat_grads.clone()))
-    assert all(np.isfinite(r[0]) for r in res) and abs(res[0][0] - np.log(cfg.vocab)) < 0.5
+    assert all(np.isfinite(r[0]) for r in res) and abs(res[0][0] - ev[0]) < 0.1
     assert m.last_active_length == int((lab != cfg.pad_id).sum(1).max())
     gmax = res[0][1].abs().max().item()
     assert torch.isfinite(res[0][1]).all() and gmax > 0
-    assert abs(res[0][0] - res[1][0]) < 1e-5 and (res[0][1] - res[1][1]).abs().max().item() < 1e-3 * gmax      # same seed
-    assert abs(res[0][0] - res[2][0]) < 1e-4 and (res[0][1] - res[2][1]).abs().max().item() < 1e-3 * gmax      # trim is exact
-    assert (res[0][1] - res[3][1]).abs().max().item() > 1e-2 * gmax                                            # another mask
-    # gradient norm per tensor against a B=2 oracle is covered by the fixture tests; here: every tensor received a gradient
+    assert abs(res[0][0] - res[1][0]) < 1e-4 and (res[0][1] - res[1][1]).abs().max().item() < 1e-3 * gmax      # same seed
+    assert (res[0][1] - res[2][1]).abs().max().item() > 1e-2 * gmax                                            # another mask
+    # per-tensor gradient parity against the oracle is the B = 2 fixture's job; here: every tensor received a gradient
     for k, v in m.grad_dict().items():
         if not k.endswith("key.bias") and "token_type" not in k:
             assert v.abs().max().item() > 0, k
@@ -120,7 +140,7 @@ def test_two_rank_stepper_on_one_gpu(tmp_path):
     assert r0["norms"] == r1["norms"]                         # the clip saw the same (reduced) gradient on both ranks
     # single process: per-rank gradients averaged by hand, then clip + step on the averaged gradient
     cfg = W.run_config()
-    m = _make(cfg, tmp_path, 4, learning_rate=W.LR)
+    m = _make(cfg, tmp_path, 4, learning_rate=W.LR, beta2=W.BETA2)
     opt = m.configure_optimizers()
     m.train()
     for step in range(W.STEPS):

@@ -50,9 +50,10 @@ def test_resize_with_padding_known_answer():
     assert torch.all(t[:, :256] == 1.0) and torch.all(t[:, 300:700] < 0.1)
 
 
-def test_csv_dataset_item_contract(tmp_path):
+def test_csv_dataset_item_contract(tmp_path, monkeypatch):
     from PIL import Image
     from transformers import AutoTokenizer
+    from kzv.data import reference_image_path
     cfg = tiny_config()
     tok = AutoTokenizer.from_pretrained(build_decoder_dir(str(tmp_path / "dec"), cfg))
     root = tmp_path / "imgs"
@@ -61,22 +62,55 @@ def test_csv_dataset_item_contract(tmp_path):
     for i in range(10):
         Image.new("RGB", (40 + i, 300), (i * 20, 0, 0)).save(root / f"c{i}.png")
         ids = ["U+4E00", "U+4E01", "U+4E02"][: 1 + i % 3]
-        rows.append(f'c{i}.png,"{ids}"')
-    rows.append('missing.png,"[\'U+4E00\']"')
+        rows.append(f'imgs/c{i}.png,"{ids}"')                      # relative to the working directory (trocr_dataset.py:129)
+    (root / "broken.png").write_bytes(b"not a png")                # exists but cannot be decoded -> zeros (:182-185)
+    rows.append('imgs/broken.png,"[\'U+4E00\']"')
+    rows.insert(3, 'imgs/missing.png,"[\'U+4E00\']"')            # does not exist -> dropped BEFORE the split (:135)
     csv = tmp_path / "column_info.csv"
     csv.write_text("column_image,unicode_ids\n" + "\n".join(rows) + "\n", encoding="utf-8")
-    ds = {s: LineCsvDataset(str(csv), str(root), tok, image_size=(32, 64), max_length=8, split=s) for s in ("train", "val", "test")}
-    assert [len(ds[s]) for s in ("train", "val", "test")] == [8, 1, 2]       # int(11*0.8), int(11*0.9)
+    monkeypatch.chdir(tmp_path)
+    # the reference's path rules
+    assert reference_image_path("/abs/x.png") == "/abs/x.png"
+    assert reference_image_path("processed_v2/column_images/a/b.jpg") == "data/processed_v2/column_images/a/b.jpg"
+    assert reference_image_path("imgs/c0.png") == str(tmp_path / "imgs" / "c0.png")
+    ds = {s: LineCsvDataset(str(csv), "unused", tok, image_size=(32, 64), max_length=8, split=s) for s in ("train", "val", "test")}
+    assert [len(ds[s]) for s in ("train", "val", "test")] == [8, 1, 2]       # 11 existing rows: int(11*0.8), int(11*0.9)
+    assert ds["train"][3]["image_path"].endswith("c3.png")                    # the missing row did not shift into the slice
     it = ds["train"][1]
     assert tuple(it["pixel_values"].shape) == (3, 32, 64) and it["labels"].dtype == torch.int64
     assert it["labels"].tolist()[:2] == [5, 6] and it["labels"].tolist()[2:] == [1] * 6 and it["text"] == "一丁"
-    bad = ds["test"][1]                                                        # unreadable image -> zeros
-    assert torch.all(bad["pixel_values"] == 0)
+    bad = ds["test"][1]                                                        # undecodable image -> zeros
+    assert bad["image_path"].endswith("broken.png") and torch.all(bad["pixel_values"] == 0)
     with pytest.raises(ValueError):
         LineCsvDataset(str(csv), str(root), tok, split="dev")
+    monkeypatch.chdir("/")                                                     # relocated dataset: the image_root extension
+    assert len(LineCsvDataset(str(csv), str(root), tok, image_size=(32, 64), max_length=8, split="train")) == 0
+    assert len(LineCsvDataset(str(csv), str(root), tok, image_size=(32, 64), max_length=8, split="train", resolve="image_root")) == 8
+    monkeypatch.chdir(tmp_path)
     loader = make_loader(ds["train"], 4, shuffle=True, rank=1, world=2)
     b = next(iter(loader))
     assert tuple(b["pixel_values"].shape) == (4, 3, 32, 64) and tuple(b["labels"].shape) == (4, 8)
+
+
+def test_loader_reshuffles_every_epoch_and_shards_like_a_distributed_sampler():
+    """DataLoader(shuffle=True) (src/data/trocr_dataset.py:256-262) + Lightning's DistributedSampler: a new permutation per
+    epoch (seed + epoch), identical on every rank, padded to a multiple of the world size, strided by rank; no drop_last."""
+    cfg = tiny_config()
+    ds = SyntheticLineDataset(cfg, 11, 8)
+
+    def order(loader, epoch):
+        loader.set_epoch(epoch)
+        return sum((b["image_path"] for b in loader), [])
+    l0, l1 = make_loader(ds, 4, True, seed=42, rank=0, world=2), make_loader(ds, 4, True, seed=42, rank=1, world=2)
+    e0, e1 = order(l0, 0), order(l0, 1)
+    assert e0 != e1 and order(l0, 0) == e0                       # reshuffled per epoch, reproducible
+    both = e0 + order(l1, 0)
+    assert len(e0) == 6 and len(both) == 12 and set(both) == {f"synthetic://{i}" for i in range(11)}    # padded by one repeat
+    single = make_loader(ds, 4, True, seed=42)
+    assert [len(b["image_path"]) for b in single] == [4, 4, 3]   # drop_last=False like the reference
+    perm = order(single, 0)
+    assert e0 == perm[0::2] and order(l1, 0) == (perm + perm[:1])[1::2]
+    assert order(make_loader(ds, 4, False), 3) == [f"synthetic://{i}" for i in range(11)]
 
 
 def test_synthetic_dataset_and_sharding():
@@ -160,7 +194,8 @@ def test_train_cli_flag_surface():
     from kzv.train import parse_args
     a = parse_args([])
     # defaults of scripts/train_trocr.py:23-71
-    assert (a.image_size, a.patch_size, a.encoder_hidden_size, a.encoder_num_layers, a.encoder_num_heads) == ([1024, 64], [16, 16], 768, 12, 8)
+    assert (a.image_size, a.patch_size, a.encoder_hidden_size, a.encoder_num_layers) == ([1024, 64], [16, 16], 768, 12)
+    assert a.encoder_num_heads == 12      # NOT the reference's 8 (head_dim 96): the attention kernels are built for head_dim 64 (kzv/train.py help)
     assert (a.batch_size, a.learning_rate, a.weight_decay, a.beta1, a.beta2, a.epsilon, a.max_epochs) == (64, 1e-4, 0, 0.9, 0.999, 1e-8, 50)
     assert (a.gpus, a.precision, a.max_length, a.num_workers) == (1, "bf16-mixed", 128, 8)
     b = parse_args(["--train_data_dir", "x", "--val_data_dir", "y", "--accelerator", "gpu", "--devices", "2", "--seed", "7"])

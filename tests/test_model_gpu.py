@@ -360,7 +360,9 @@ def test_train_cli_two_epochs_synthetic_writes_checkpoints(tmp_path):
     import torch
     sd = torch.load(ck / "last.ckpt", map_location="cpu", weights_only=False)
     assert "encoder.patch_embeddings.projection.weight" in sd["state_dict"]
-    assert sd["optimizer_states"][0]["k"] == 4       # 2 epochs x 2 steps
+    assert sd["optimizer_states"][0]["param_groups"][0]["k"] == 4       # 2 epochs x 2 steps (schedulefree's layout)
+    assert sd["pytorch-lightning_version"] and "hyper_parameters" in sd
+    assert main.test_metrics is not None and np.isfinite(main.test_metrics["test_loss"])      # the post-fit test phase ran
 
 
 def test_ema_callback_matches_reference_update_rule(tmp_path):

@@ -113,10 +113,12 @@ def test_dataset_with_device_preprocess_equals_the_host_transform(tmp_path):
     for k, (h, w) in enumerate([(100, 30), (210, 17), (64, 32), (33, 64), (500, 40)]):
         Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(root / f"c{k}.png")
         rows.append(f"c{k}.png,\"['U+4E00', 'U+4E01']\"")
-    rows.append("missing.png,\"['U+4E00']\"")
+    (root / "broken.png").write_bytes(b"not an image")       # exists, cannot be decoded -> all-zero tensor (trocr_dataset.py:182-185)
+    rows.append("broken.png,\"['U+4E00']\"")
+    rows.append("missing.png,\"['U+4E00']\"")              # does not exist -> dropped (trocr_dataset.py:135)
     csv = tmp_path / "column_info.csv"
     csv.write_text("column_image,unicode_ids\n" + "\n".join(rows) + "\n", encoding="utf-8")
-    kw = dict(image_size=(64, 32), max_length=8, split="train", train_ratio=1.0, val_ratio=0.0, test_ratio=0.0)
+    kw = dict(image_size=(64, 32), max_length=8, split="train", train_ratio=1.0, val_ratio=0.0, test_ratio=0.0, resolve="image_root")
     host = LineCsvDataset(str(csv), str(root), tok, **kw)
     dev = LineCsvDataset(str(csv), str(root), tok, device_preprocess=True, **kw)
     assert len(host) == len(dev) == 6
