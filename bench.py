@@ -8,8 +8,9 @@ all-reduce + clip 1.0 + RAdamScheduleFree + bf16 weight refresh), synthetic 64x6
 
 Prints ONE JSON line (rank 0).  value = line-images/s of the whole job (all ranks), inputs resident in HBM.
 roofline: the bf16 MFMA GEMM family gemm_nt_kernel<*> (every nn.Linear forward and input-gradient), timed live
-with HIP events around each of its launches inside the timed region (kzv_prof_*), priced by its algorithmic
-2*M*N*K FLOPs against the 2.5 PFLOP/s dense bf16 peak of /opt/skills/guides/MI355X_MICROARCH.md.
+with HIP events inside the timed region (kzv_prof_*: every 4th launch is bracketed -- a bracket costs ~2 us of stream
+time, and 4 is co-prime to the launches per step, so every launch site is sampled equally often), priced by its
+algorithmic 2*M*N*K FLOPs against the 2.5 PFLOP/s dense bf16 peak of /opt/skills/guides/MI355X_MICROARCH.md.
 cpu_baseline: oracle/trocr_oracle.py (a port, not the reference) timed on this box's host cores, rank 0, N=1.
 """
 from __future__ import annotations
@@ -46,8 +47,20 @@ def train_flops_per_image(cfg, T):
     return 3.0 * fwd
 
 
+def source_sha16():
+    """Identity of the kernel sources a profile belongs to (tools/hbm_traffic.py stores it; bench.py only quotes
+    `traffic` from a profile taken on the SAME sources)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "kuzushiji-vision_amd", "csrc", "*.[hc]*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(cfg, label_len, sample_batch, steps):
-    """Oracle (CPU port) train step: fwd + CE + autograd bwd + clip + RAdamScheduleFree, fp32, all host cores."""
+    """Oracle (CPU port) train step like the timed GPU step: fwd (dropout 0.1 ON, masks drawn per site with torch.rand) +
+    CE + autograd bwd + clip + RAdamScheduleFree, fp32, all host cores."""
     import numpy as np
     import torch
     from kzv import params as P
@@ -59,12 +72,28 @@ def cpu_baseline(cfg, label_len, sample_batch, steps):
     st = O.RAdamScheduleFreeState()
     z = {k: v.detach().clone() for k, v in sd.items()}
     vv = {k: torch.zeros_like(v) for k, v in sd.items()}
+    B, T, Se = sample_batch, label_len - 1, cfg.enc_seq
+
+    def draw_masks():      # what nn.Dropout / F.dropout do in the reference's training mode (19 % of its CPU step)
+        def mk(shape, p):
+            return (torch.rand(shape) >= p).float() / (1.0 - p)
+        m = {"enc_emb": mk((B, Se, cfg.enc_hidden), cfg.enc_hidden_dropout), "dec_emb": mk((B, T, cfg.dec_hidden), cfg.dec_hidden_dropout)}
+        for i in range(cfg.enc_layers):
+            m[f"enc{i}_attn"] = mk((B, cfg.enc_heads, Se, Se), cfg.enc_attn_dropout)
+            m[f"enc{i}_o"] = mk((B, Se, cfg.enc_hidden), cfg.enc_hidden_dropout)
+            m[f"enc{i}_mlp"] = mk((B, Se, cfg.enc_hidden), cfg.enc_hidden_dropout)
+        for i in range(cfg.dec_layers):
+            m[f"dec{i}_sa"] = mk((B, cfg.dec_heads, T, T), cfg.dec_attn_dropout)
+            m[f"dec{i}_ca"] = mk((B, cfg.dec_heads, T, cfg.num_patches), cfg.dec_attn_dropout)
+            for sfx in ("sa_o", "ca_o", "ffn"):
+                m[f"dec{i}_{sfx}"] = mk((B, T, cfg.dec_hidden), cfg.dec_hidden_dropout)
+        return m
     times = []
     for it in range(steps + 1):
         t0 = time.perf_counter()
         for v in sd.values():
             v.grad = None
-        _, loss = O.forward(cfg, sd, px_t, lab_t)
+        _, loss = O.forward(cfg, sd, px_t, lab_t, masks=draw_masks())
         loss.backward()
         grads = [v.grad for v in sd.values()]
         total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads)))
@@ -83,7 +112,7 @@ def cpu_baseline(cfg, label_len, sample_batch, steps):
     dt = float(np.mean(times))
     return {"value": sample_batch / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} train steps (after 1 warm-up) of batch {sample_batch} on the same geometry, fp32, "
-                      f"dropout off, oracle/trocr_oracle.py with torch CPU autograd; {dt:.2f} s/step"}
+                      f"dropout 0.1 on, oracle/trocr_oracle.py with torch CPU autograd; {dt:.2f} s/step"}
 
 
 def main():
@@ -137,8 +166,10 @@ def main():
     # Timed region: HIP events bracket every launch of the reported kernel family only (each bracket costs ~2 us of
     # stream time; gemm_tn / attention are measured in one extra, untimed step below).
     events = not os.environ.get("KZV_BENCH_NO_EVENTS")     # dev knob: step time without any per-launch events
+    stride = int(os.environ.get("KZV_BENCH_EVENT_STRIDE", "4"))
     if events:
         L.check(lib.kzv_prof_select(1 << 0), "prof_select")
+        L.check(lib.kzv_prof_sample(stride), "prof_sample")
         L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -148,7 +179,9 @@ def main():
     L.check(lib.kzv_prof_enable(0, 0), "prof_disable")
     nt_ms, nt_fl, nt_n = C.c_double(), C.c_double(), C.c_int64()
     L.check(lib.kzv_prof_collect(0, C.byref(nt_ms), C.byref(nt_fl), C.byref(nt_n)), "prof_collect")
+    nt_seen = int(lib.kzv_prof_seen(0))
     if events:                                             # untimed: one more step for the other kernel families
+        L.check(lib.kzv_prof_sample(1), "prof_sample")
         L.check(lib.kzv_prof_select((1 << 1) | (1 << 2) | (1 << 3)), "prof_select")
         L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
         stepper.step(batch, args.steps)
@@ -180,12 +213,18 @@ def main():
                             "launches_per_step": n2, "measured": "one extra step outside the timed region"}
         DECPOS = (f"{t_act} of {T} computed: columns that are padding in every sample of the batch are skipped (exact: masked "
                   "keys, ignored targets); labels hold U{8..60} characters (BASELINE.md section 4)")
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tj) and args.batch == 256 and args.dec_layers == 6:   # measured offline on this exact workload
-            k = json.load(open(tj))["kernels"].get("gemm_nt_kernel<*>")
-            if k:
-                traffic = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+        # HBM-side bytes per launch come from rocprofv3 PMC passes (they cannot be collected from inside this process):
+        # quoted only from a profile of THIS workload taken on THESE kernel sources (tools/hbm_traffic.py records their hash),
+        # null otherwise -- never from a stale file
+        traffic, traffic_src = None, None
+        import glob
+        for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+            j = json.load(open(tj))
+            if j.get("source_sha16") == source_sha16() and args.batch == 256 and args.dec_layers == 6 and args.encoder == "vit_b":
+                k = j["kernels"].get("gemm_nt_kernel<*>")
+                if k:
+                    traffic, traffic_src = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], os.path.relpath(tj, ROOT)
+                    break
         out = {
             "metric": "line-images/sec (train)", "value": imgs / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -198,9 +237,11 @@ def main():
                        "final_loss": final_loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> (bf16 MFMA 16x16x32, all nn.Linear fwd + dgrad)",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss fetch x2-corrected + write, rocprofv3 PMC, profiles/r01_hbm_traffic.json)",
-                         "launches_per_step": n / args.steps, "avg_launch_us": (ms / n * 1e3) if n else None,
-                         "kernel_ms_per_step": ms / args.steps,
+                         "traffic": traffic, "traffic_unit": f"bytes/launch (L2-miss fetch x2-corrected + write, rocprofv3 PMC, {traffic_src}; null = no profile of these kernel sources)",
+                         "launches_per_step": nt_seen / args.steps, "avg_launch_us": (ms / n * 1e3) if n else None,
+                         "kernel_ms_per_step": (ms / n * nt_seen / args.steps) if n else None,
+                         "events": f"every {stride}th launch bracketed inside the timed region ({n} of {nt_seen} launches)",
+                         "source_sha16": source_sha16(),
                          "whole_step_TFLOP/s": step_flops / (dt / args.steps) / 1e12,
                          "whole_step_frac": step_flops / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
                          "other_kernels": others},

@@ -198,6 +198,11 @@ int kzv_attn_bwd(const kzv_attn_args* a, void* stream);
 int kzv_prof_enable(int on, int capacity);
 int kzv_prof_select(unsigned kind_mask);
 int kzv_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches);
+/* Sampling: bracket only every `stride`-th launch of each selected kind (default 1 = all).  A bracket costs ~2 us of stream
+ * time; with a stride co-prime to the launches per step every launch site is sampled equally often over `stride` steps.
+ * kzv_prof_collect then sums the SAMPLED launches; kzv_prof_seen = launches of that kind seen since kzv_prof_enable(1, n). */
+int kzv_prof_sample(int stride);
+int64_t kzv_prof_seen(int kind);
 uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
 
 /* Dropout call sites of the training step (nn.Dropout / F.dropout in the reference).  kzv_forward_loss(train=1, seed) keys

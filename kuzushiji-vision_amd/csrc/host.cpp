@@ -71,10 +71,14 @@ std::vector<ProfRec> g_prof;
 size_t g_prof_used = 0;
 bool g_prof_on = false;
 unsigned g_prof_mask = ~0u;
+int g_prof_stride = 1;
+int64_t g_prof_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 }  // namespace
 
 KzvProfScope::KzvProfScope(int kind, double work, hipStream_t stream) : slot(-1), s(stream) {
-    if (!g_prof_on || !((g_prof_mask >> kind) & 1u) || g_prof_used >= g_prof.size()) return;
+    if (!g_prof_on || !((g_prof_mask >> kind) & 1u)) return;
+    const int64_t seen = g_prof_seen[kind & 7]++;
+    if (seen % g_prof_stride || g_prof_used >= g_prof.size()) return;
     slot = (int)g_prof_used++;
     g_prof[slot].kind = kind; g_prof[slot].work = work;
     (void)hipEventRecord(g_prof[slot].a, s);
@@ -91,12 +95,19 @@ extern "C" int kzv_prof_enable(int on, int capacity) {
             g_prof.push_back(r);
         }
         g_prof_used = 0;
+        for (int i = 0; i < 8; ++i) g_prof_seen[i] = 0;
     }
     g_prof_on = on != 0;
     return KZV_OK;
 }
 
 extern "C" int kzv_prof_select(unsigned kind_mask) { g_prof_mask = kind_mask; return KZV_OK; }
+extern "C" int kzv_prof_sample(int stride) {
+    if (stride < 1) return kzv_fail(KZV_E_ARG, "prof_sample: stride >= 1");
+    g_prof_stride = stride;
+    return KZV_OK;
+}
+extern "C" int64_t kzv_prof_seen(int kind) { return kind >= 0 && kind < 8 ? g_prof_seen[kind] : 0; }
 
 // Sums the recorded launches of `kind` (call after the stream is synchronised): total ms, total work units
 // (FLOPs), launch count.  Does not reset; kzv_prof_enable(1, n) starts a new recording.

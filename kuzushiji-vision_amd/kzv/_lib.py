@@ -96,6 +96,8 @@ SYMBOLS = {
     "kzv_debug_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "kzv_prof_select": (C.c_int, [C.c_uint]),
+    "kzv_prof_sample": (C.c_int, [C.c_int]),
+    "kzv_prof_seen": (C.c_int64, [C.c_int]),
     "kzv_set_cu_reserve": (C.c_int, [C.c_int]),
     "kzv_decode_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kzv_decode_reorder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -10,9 +10,21 @@ also summed as the family "gemm_nt_kernel<*>" that bench.py's roofline reports.
 """
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha16():      # same recipe as bench.py::source_sha16
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "kuzushiji-vision_amd", "csrc", "*.[hc]*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name: str) -> str:
@@ -51,6 +63,7 @@ def main():
             "fetch_bytes_per_launch": sum(out[k]["fetch_bytes_per_launch"] * out[k]["launches"] for k in fam) / nl,
             "write_bytes_per_launch": sum(out[k]["write_bytes_per_launch"] * out[k]["launches"] for k in fam) / nl}
     print(json.dumps({
+        "source_sha16": source_sha16(),
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (two separate passes), tools/hbm_traffic.py",
         "corrections": "counter unit KiB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)",
         "note": "FETCH_SIZE counts L2-side fabric requests (Infinity-Cache hits included), i.e. L2 misses, an upper bound on HBM reads",
