@@ -75,6 +75,14 @@ int kzv_model_sync_weights(kzv_model* m, void* stream);
 int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels,
                      float* d_loss, float* d_logits, int train, uint64_t seed, void* stream);
 
+/* Width buckets (BASELINE.json configs[4]; beyond the reference, whose model instance has ONE image size,
+ * src/models/trocr_model.py:83-86,113-115).  The handle is created for the WIDEST crop (cfg.image_w, which sizes the
+ * position table and the workspace); a batch of narrower crops [B, C, H, width] runs with (H/ph) * (width/pw) patches:
+ * patch (h, w) takes the position row of (h, w) in the widest grid -- for the sin/cos table (trocr_model.py:154-167) that
+ * IS the closed-form table of the narrow grid, because an entry depends on (w, h) only.  width must be a multiple of
+ * the patch width, <= cfg.image_w.  Applies to the following kzv_forward_loss (default after create: cfg.image_w). */
+int kzv_set_image_width(kzv_model* m, int width);
+
 /* Position-id overflow check of the LAST kzv_forward_loss / kzv_decode_logits on this handle: RoBERTa's position ids
  * (count of non-pad decoder inputs + pad_id, HF modeling_roberta.py:142-155) must index the [max_pos, H] table; the reference
  * raises "index out of range" for longer labels, the kernels clamp and raise a device flag.  Synchronises `stream`, reads the
@@ -106,6 +114,15 @@ int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos, float* d_l
 int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, int t, const uint8_t* d_valid, int64_t ld_valid,
                     float* d_logits, void* stream);
 int kzv_decode_reorder(kzv_model* m, const int64_t* d_rows, int len, void* stream);
+/* The same step replayed from a hipGraph (the eager step is ~100 small launches and host-bound at ~0.85 ms per token):
+ * the step index lives in device memory -- kzv_decode_begin resets it to 0, every kzv_decode_step_graph runs step t and
+ * leaves t + 1 -- so one instantiated graph serves every step of a generation.  The graph is captured on the first call
+ * and re-captured whenever a buffer pointer (or the cache copy in use after kzv_decode_reorder) differs from the captured
+ * one: keep d_tokens / d_posids / d_valid / d_logits in fixed buffers.  `stream` must not be the default stream.  The
+ * active image width / weights must not change between kzv_decode_begin and the last step. */
+int kzv_decode_begin(kzv_model* m, void* stream);
+int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, const uint8_t* d_valid, int64_t ld_valid,
+                          float* d_logits, void* stream);
 
 /* loss.backward() for the step above: fills the bound fp32 grad buffer (which must be zero on entry;
  * kzv_zero_grads does that).  Backward is split in `kzv_backward_segments()` segments so the host can

@@ -21,6 +21,7 @@ struct DecAttnP {
     bf16_t* out; int64_t ldo;
     int nkeys, append_at, heads;                  // append_at >= 0: write knew/vnew at key index append_at first
     float scale;
+    const int* tptr;                              // non-null: the step index t lives in device memory (graph replay): nkeys = t + 1, append_at = t
 };
 
 template <int NU>
@@ -30,9 +31,12 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, lane = threadIdx.x;
     bf16_t* Kb = p.K + (int64_t)b * p.kb + h * 64;
     bf16_t* Vb = p.V + (int64_t)b * p.kb + h * 64;
-    if (p.append_at >= 0) {                       // lane d copies dimension d of the new key and value into the cache
-        Kb[(int64_t)p.append_at * p.kj + lane] = p.knew[(int64_t)b * p.ldnew + h * 64 + lane];
-        Vb[(int64_t)p.append_at * p.kj + lane] = p.vnew[(int64_t)b * p.ldnew + h * 64 + lane];
+    const int tdev = p.tptr ? *p.tptr : 0;
+    const int nkeys = p.tptr ? min(tdev + 1, 64 * NU) : p.nkeys;
+    const int append_at = p.tptr ? min(tdev, 64 * NU - 1) : p.append_at;
+    if (append_at >= 0) {                         // lane d copies dimension d of the new key and value into the cache
+        Kb[(int64_t)append_at * p.kj + lane] = p.knew[(int64_t)b * p.ldnew + h * 64 + lane];
+        Vb[(int64_t)append_at * p.kj + lane] = p.vnew[(int64_t)b * p.ldnew + h * 64 + lane];
     }
     qs[lane] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + lane]) * p.scale;
     __syncthreads();                              // cache row + query visible to the whole wave
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
     for (int u = 0; u < NU; ++u) {
         const int j = lane + 64 * u;
         sc[u] = -INFINITY;
-        if (j < p.nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) {
+        if (j < nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) {
             const bf16x8* kr = (const bf16x8*)(Kb + (int64_t)j * p.kj);
             float a = 0.f;
 #pragma unroll
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
     for (int u = 0; u < NU; ++u) prob[lane + 64 * u] = sc[u] * inv;
     __syncthreads();
     float o = 0.f;
-    for (int j = 0; j < p.nkeys; ++j) o += prob[j] * bf2f(Vb[(int64_t)j * p.kj + lane]);
+    for (int j = 0; j < nkeys; ++j) o += prob[j] * bf2f(Vb[(int64_t)j * p.kj + lane]);
     p.out[(int64_t)b * p.ldo + h * 64 + lane] = f2bf(o);
 }
 
@@ -82,13 +86,21 @@ __global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict
     dst[lo + (int64_t)b * Tmax * chunks_per_row + r] = src[lo + idx[b] * (int64_t)Tmax * chunks_per_row + r];
 }
 
+__global__ void step_inc_kernel(int* t) { *t += 1; }
+
 }  // namespace
 
+int kzv_step_inc(int* d_t, hipStream_t s) {
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, d_t);
+    return kzv_check_launch("step_inc");
+}
+
+// tptr != nullptr: self-attention of graph-replayed step `*tptr` (nkeys = the cache capacity, which picks the kernel)
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
-                    int append_at, hipStream_t s) {
+                    int append_at, hipStream_t s, const int* tptr) {
     if (nkeys < 1 || nkeys > 320) return kzv_fail(KZV_E_ARG, "attn_decode: 1..320 keys");
-    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f};
+    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr};
     if (nkeys <= 192) hipLaunchKernelGGL(attn_decode_kernel<3>, dim3(B * heads), dim3(64), 0, s, p);
     else hipLaunchKernelGGL(attn_decode_kernel<5>, dim3(B * heads), dim3(64), 0, s, p);
     return kzv_check_launch("attn_decode");

@@ -35,9 +35,16 @@ __global__ void im2row_kernel(const float* __restrict__ px, bf16_t* __restrict__
 }
 
 // -------------------------------------------------------------------------------- embed assemble (+bwd)
+// position row of token s (0 = CLS): patch p = s - 1 of a gw-wide grid sits at (p / gw, p % gw) of the gw_max-wide table
+__device__ __forceinline__ int pos_row(int s, int gw, int gw_max) {
+    if (s == 0 || gw == gw_max) return s;
+    const int pch = s - 1;
+    return 1 + (pch / gw) * gw_max + pch % gw;
+}
+
 __global__ void embed_assemble_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                       const float* __restrict__ pos, float* __restrict__ x0, int B, int np, int He,
-                                      unsigned thr16, float inv_keep, unsigned key) {
+                                      unsigned thr16, float inv_keep, unsigned key, int gw, int gw_max) {
     const int S = np + 1, h4 = He / 4;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)B * S * h4) return;
@@ -45,7 +52,7 @@ __global__ void embed_assemble_kernel(const float* __restrict__ pe, const float*
     const int64_t row = t / h4;
     const int s = row % S, b = (int)(row / S);
     const float4 a = s == 0 ? ((const float4*)cls)[c] : ((const float4*)(pe + ((int64_t)b * np + s - 1) * He))[c];
-    const float4 p = ((const float4*)(pos + (int64_t)s * He))[c];
+    const float4 p = ((const float4*)(pos + (int64_t)pos_row(s, gw, gw_max) * He))[c];
     float o0 = a.x + p.x, o1 = a.y + p.y, o2 = a.z + p.z, o3 = a.w + p.w;
     if (thr16) {
         const unsigned e = (unsigned)row * (unsigned)He + 4u * c;
@@ -59,7 +66,7 @@ __global__ void embed_assemble_kernel(const float* __restrict__ pe, const float*
 // thread = (s, 4 columns): loops over the batch; writes dpatch (bf16), dpos (+= sum_b), dcls, patch-bias grad.
 __global__ void embed_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t* __restrict__ dpatch, float* dcls,
                                           float* dpos, float* dpbias, int B, int np, int He, unsigned thr16,
-                                          float inv_keep, unsigned key) {
+                                          float inv_keep, unsigned key, int gw, int gw_max) {
     const int S = np + 1, h4 = He / 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S * h4) return;
@@ -77,7 +84,7 @@ __global__ void embed_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t*
         a0 += d.x; a1 += d.y; a2 += d.z; a3 += d.w;
         if (s > 0) ((uint2*)(dpatch + ((int64_t)b * np + s - 1) * He))[c] = make_uint2(pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
     }
-    float* dp = dpos + (int64_t)s * He + 4 * c;
+    float* dp = dpos + (int64_t)pos_row(s, gw, gw_max) * He + 4 * c;
     dp[0] += a0; dp[1] += a1; dp[2] += a2; dp[3] += a3;
     if (s == 0) {
         float* dc = dcls + 4 * c;
@@ -306,18 +313,20 @@ int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph,
 }
 
 int kzv_embed_assemble(const float* pe, const float* cls, const float* pos, float* x0, int B, int np, int He,
-                       float drop_p, uint32_t key, hipStream_t s) {
+                       float drop_p, uint32_t key, hipStream_t s, int gw, int gw_max) {
     unsigned thr; float ik; kzv_drop_params(drop_p, &thr, &ik);
     const int64_t total = (int64_t)B * (np + 1) * (He / 4);
-    hipLaunchKernelGGL(embed_assemble_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, pe, cls, pos, x0, B, np, He, thr, ik, key);
+    if (gw <= 0 || gw_max <= 0) gw = gw_max = 1;
+    hipLaunchKernelGGL(embed_assemble_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, pe, cls, pos, x0, B, np, He, thr, ik, key, gw, gw_max);
     return kzv_check_launch("embed_assemble");
 }
 
 int kzv_embed_assemble_bwd(const float* dx0, bf16_t* dpatch, float* dcls, float* dpos, float* dpbias, int B, int np, int He,
-                           float drop_p, uint32_t key, hipStream_t s) {
+                           float drop_p, uint32_t key, hipStream_t s, int gw, int gw_max) {
     unsigned thr; float ik; kzv_drop_params(drop_p, &thr, &ik);
     const int total = (np + 1) * (He / 4);
-    hipLaunchKernelGGL(embed_assemble_bwd_kernel, dim3(nblk(total, 64)), dim3(64), 0, s, dx0, dpatch, dcls, dpos, dpbias, B, np, He, thr, ik, key);
+    if (gw <= 0 || gw_max <= 0) gw = gw_max = 1;
+    hipLaunchKernelGGL(embed_assemble_bwd_kernel, dim3(nblk(total, 64)), dim3(64), 0, s, dx0, dpatch, dcls, dpos, dpbias, B, np, He, thr, ik, key, gw, gw_max);
     return kzv_check_launch("embed_assemble_bwd");
 }
 

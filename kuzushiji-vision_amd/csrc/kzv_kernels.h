@@ -14,10 +14,11 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
 
 // elementwise.hip
 int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s);
+// gw / gw_max: patches per grid row of this batch / of the position table (width buckets: row of patch p = (p / gw) * gw_max + p % gw)
 int kzv_embed_assemble(const float* patch_emb, const float* cls, const float* pos, float* x0, int B, int np, int He,
-                       float drop_p, uint32_t key, hipStream_t s);
+                       float drop_p, uint32_t key, hipStream_t s, int gw = 0, int gw_max = 0);
 int kzv_embed_assemble_bwd(const float* dx0, bf16_t* dpatch, float* dcls, float* dpos, float* dpatch_bias, int B, int np,
-                           int He, float drop_p, uint32_t key, hipStream_t s);
+                           int He, float drop_p, uint32_t key, hipStream_t s, int gw = 0, int gw_max = 0);
 int kzv_cast_drop_colsum(const float* g, bf16_t* out, float* dbias, int M, int N, float drop_p, uint32_t key, hipStream_t s,
                          const bf16_t* gelu_pre = nullptr);
 int kzv_colsum_bf16(const bf16_t* g, int64_t ld, float* dbias, int M, int N, hipStream_t s);
@@ -44,5 +45,6 @@ int kzv_sqnorm(const float* g, int64_t n, float* out1, float* scratch, hipStream
 // decode.hip (KV-cached generation step)
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
-                    int append_at, hipStream_t s);
+                    int append_at, hipStream_t s, const int* tptr = nullptr);
+int kzv_step_inc(int* d_t, hipStream_t s);
 int kzv_kv_reorder(const bf16_t* src, bf16_t* dst, const int64_t* idx, int layers2, int B, int Tmax, int len, int Hd, hipStream_t s);

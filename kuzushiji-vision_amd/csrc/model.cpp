@@ -40,6 +40,7 @@ struct DecAct {
 struct kzv_model {
     kzv_config c;
     int np, Se, PD, He, Fe, Hd, Fd, V, Vp, Le, Ld;
+    int npa = 0, Sa = 0, img_w = 0;   // ACTIVE geometry (kzv_set_image_width): img_w <= c.image_w, npa patches, Sa = npa + 1 tokens
     bool has_proj;
     std::vector<PEntry> table;
     int64_t total = 0;
@@ -74,6 +75,11 @@ struct kzv_model {
     bool pending[4] = {false, false, false, false}; bool use_side = false, join_each_segment = true;
     // KV cache of the generation path (kzv_decode_step): two copies [2*Ld][B][T][Hd] (beam re-ordering gathers from one into the other)
     bf16_t* kvc[2] = {nullptr, nullptr}; int kv_cur = 0, kvB = 0, kvT = 0;
+    // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
+    int* d_t = nullptr;
+    hipGraphExec_t dgraph[2] = {nullptr, nullptr};
+    const void* dg_key[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    int64_t dg_ld[2] = {0, 0};
     bool side_ok = false;    // mode 2: set only inside the encoder-layer schedule (everything else stays on the caller's stream)
     int side_mode = 0;       // 0 off, 1 free-running wgrads, 2 wgrads only under the HBM-bound kernels (LayerNorm / attention backward)
 };
@@ -192,6 +198,7 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
 
     // scalars
     m->count = b.take<float>(64); m->loss_acc = m->count + 1; m->err = (int*)(m->count + 2);
+    m->d_t = (int*)b.take<float>(64);
     m->posids = b.take<int>(Md);
     // encoder activations
     m->patches = b.take<bf16_t>(Mp * m->PD);
@@ -313,7 +320,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     // T = ACTIVE decoder length (kzv_set_active_length): positions >= T hold only padding in every sample, are
     // masked as keys and carry no loss, so the decoder runs on the packed [B, T] prefix (rows b*T + t).
     const int B = m->B, T = m->Ta, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
-    const int Me = B * m->Se, Mp = B * m->np, Md = B * T;
+    const int Me = B * m->Sa, Mp = B * m->npa, Md = B * T;
     float* P = m->P;
     const float eps = c.ln_eps;
     m->labels = labels;
@@ -321,10 +328,11 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     const int CK = m->Ld * 2 * Hd;
     if (run_encoder) {
     // ---- patch embedding: Conv2d(k=s=16) == im2row + GEMM (trocr_model.py:77,89-90) -----------------
-    KZV_TRY(kzv_im2row(px, m->patches, B, c.channels, c.image_h, c.image_w, c.patch_h, c.patch_w, s));
+    KZV_TRY(kzv_im2row(px, m->patches, B, c.channels, c.image_h, m->img_w, c.patch_h, c.patch_w, s));
     KZV_TRY(gemm(m->patches, m->PD, m->w_patch, false, Mp, He, m->PD, He, P + m->patch_b, m->pe32, He, KZV_EPI_F32, s));
     float* x0 = m->Le ? m->ea[0].x_in : m->x_last;
-    KZV_TRY(kzv_embed_assemble(m->pe32, P + m->cls, P + m->pos, x0, B, m->np, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s));
+    KZV_TRY(kzv_embed_assemble(m->pe32, P + m->cls, P + m->pos, x0, B, m->npa, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s,
+                               m->img_w / c.patch_w, c.image_w / c.patch_w));
     // ---- ViT layers (pre-LN; HF modeling_vit.py:257-286) -----------------------------------------------
     for (int i = 0; i < m->Le; ++i) {
         EncAct& a = m->ea[i];
@@ -333,7 +341,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         KZV_TRY(kzv_ln_fwd_ex(a.x_in, P + e.ln1w, P + e.ln1b, a.ln1, nullptr, a.st1, Me, He, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.ln1, He, m->w_eqkv[i], false, Me, 3 * He, He, 3 * He, P + e.qkvb, a.qkv, 3 * He, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, false, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, nullptr, nullptr, nullptr, nullptr,
-                     c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+                     c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
         KZV_TRY(gemm(a.ctx, He, m->w_eo[i], false, Me, He, He, He, P + e.ob, a.x_mid, He, KZV_EPI_RESID, s, a.x_in, nullptr, 0,
                      dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
         KZV_TRY(kzv_ln_fwd_ex(a.x_mid, P + e.ln2w, P + e.ln2b, a.ln2, nullptr, a.st2, Me, He, eps, 1, 0, 0.f, 0, s));
@@ -342,7 +350,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
                      dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 2)));
     }
     // final LN, drop CLS (trocr_model.py:197-200), projection (:269)
-    KZV_TRY(kzv_ln_fwd_ex(m->x_last, P + m->lnf_w, P + m->lnf_b, m->enc_out, nullptr, m->stf, Me, He, eps, m->Se, 1, 0.f, 0, s));
+    KZV_TRY(kzv_ln_fwd_ex(m->x_last, P + m->lnf_w, P + m->lnf_b, m->enc_out, nullptr, m->stf, Me, He, eps, m->Sa, 1, 0.f, 0, s));
     if (m->has_proj)
         KZV_TRY(gemm(m->enc_out, He, m->w_proj, false, Mp, Hd, He, Hd, P + m->proj_b, m->proj_out, Hd, KZV_EPI_BF16, s));
     // cross-attention K/V of every decoder layer in one GEMM
@@ -368,7 +376,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, Md, Hd, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, Md, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, false, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
-                     nullptr, nullptr, nullptr, nullptr, c.dec_heads, T, m->np, dp(m, c.dec_attn_dropout), key(m, site + 2), s));
+                     nullptr, nullptr, nullptr, nullptr, c.dec_heads, T, m->npa, dp(m, c.dec_attn_dropout), key(m, site + 2), s));
         KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, Md, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0,
                      dp(m, c.dec_hidden_dropout), key(m, site + 3)));
         KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, Md, Hd, eps, 1, 0, 0.f, 0, s));
@@ -403,7 +411,7 @@ int lin_bwd_drop(const float* dx, bf16_t* dy, float* dbias, int M, int N, float 
 int backward_decoder(kzv_model* m, hipStream_t s) {
     const kzv_config& c = m->c;
     const int B = m->B, T = m->Ta, Hd = m->Hd, Fd = m->Fd, He = m->He;
-    const int Mp = B * m->np, Md = B * T, Me = B * m->Se;
+    const int Mp = B * m->npa, Md = B * T, Me = B * m->Sa;
     float* P = m->P; float* G = m->G;
     const int CK = m->Ld * 2 * Hd;
     // ---- CE -> LM head ------------------------------------------------------------------------------
@@ -437,7 +445,7 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
         KZV_TRY(wait_cls(m, CLS_MISC, s));   // dq_d (and, first layer, dlogits' reader) before the cross-attention backward rewrites dq_d
         KZV_TRY(gemm(m->dy_d, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
-                     m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->np,
+                     m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->npa,
                      dp(m, c.dec_attn_dropout), key(m, site + 2), s));
         KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
         KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
@@ -466,14 +474,14 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     }
     // also emits the masked bf16 copy the top ViT layer's fc2 backward starts from
     KZV_TRY(wait_cls(m, CLS_DY, s));
-    KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Se, 1, 0.f, 0, s,
+    KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Sa, 1, 0.f, 0, s,
                           m->Le ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (m->Le - 1) + 2)));
     return KZV_OK;
 }
 
 int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     const kzv_config& c = m->c;
-    const int He = m->He, Fe = m->Fe, Me = m->B * m->Se;
+    const int He = m->He, Fe = m->Fe, Me = m->B * m->Sa;
     float* P = m->P; float* G = m->G;
     EncAct& a = m->ea[i];
     const EncLayerP& e = m->ep[i];
@@ -495,7 +503,7 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
         KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e2, He, a.ctx, He, G + e.ow, Me, He, He, He, G + e.ob));
         KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
         KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
-                     m->dqkv_e + 2 * He, c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+                     m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
         KZV_TRY(join_side(m, s));
         KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
         KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
@@ -518,7 +526,7 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     KZV_TRY(gemm(m->dy_e, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
     KZV_TRY(wait_cls(m, CLS_DQKV, s));    // dqkv_e is rewritten below
     KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
-                 m->dqkv_e + 2 * He, c.enc_heads, m->Se, m->Se, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+                 m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
     KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
     KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
     // ... and the masked copy for the fc2 site of the layer below (layer 0 hands fp32 dx_e to the embedding backward)
@@ -530,10 +538,10 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
 
 int backward_embed(kzv_model* m, hipStream_t s) {
     const kzv_config& c = m->c;
-    const int He = m->He, Mp = m->B * m->np;
+    const int He = m->He, Mp = m->B * m->npa;
     float* G = m->G;
-    KZV_TRY(kzv_embed_assemble_bwd(m->dx_e, m->dpatch, G + m->cls, G + m->pos, G + m->patch_b, m->B, m->np, He,
-                                   dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s));
+    KZV_TRY(kzv_embed_assemble_bwd(m->dx_e, m->dpatch, G + m->cls, G + m->pos, G + m->patch_b, m->B, m->npa, He,
+                                   dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s, m->img_w / c.patch_w, c.image_w / c.patch_w));
     KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dpatch, He, m->patches, m->PD, G + m->patch_w, Mp, He, m->PD, He, nullptr));
     return KZV_OK;
 }
@@ -558,6 +566,7 @@ extern "C" int kzv_model_create(const kzv_config* cfg, kzv_model** out) {
     kzv_model* m = new kzv_model();
     m->c = c;
     m->np = np; m->Se = np + 1; m->PD = c.channels * c.patch_h * c.patch_w;
+    m->npa = np; m->Sa = np + 1; m->img_w = c.image_w;
     m->He = c.enc_hidden; m->Fe = c.enc_ffn; m->Hd = c.dec_hidden; m->Fd = c.dec_ffn;
     m->V = c.vocab; m->Vp = (int)align_up(c.vocab, 64); m->Le = c.enc_layers; m->Ld = c.dec_layers;
     m->has_proj = m->He != m->Hd;
@@ -572,6 +581,7 @@ extern "C" int kzv_model_destroy(kzv_model* m) {
         if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
         for (int i = 0; i < 4; ++i) if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
         for (int i = 0; i < 2; ++i) if (m->kvc[i]) (void)hipFree(m->kvc[i]);
+        for (int i = 0; i < 2; ++i) if (m->dgraph[i]) (void)hipGraphExecDestroy(m->dgraph[i]);
     }
     delete m;
     return KZV_OK;
@@ -656,6 +666,18 @@ extern "C" int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const
     return rc;
 }
 
+extern "C" int kzv_set_image_width(kzv_model* m, int width) {
+    if (!m) return kzv_fail(KZV_E_STATE, "set_image_width: null model");
+    const kzv_config& c = m->c;
+    if (width < c.patch_w || width > c.image_w || width % c.patch_w)
+        return kzv_fail(KZV_E_ARG, "set_image_width: %d is not a multiple of the patch width %d within %d..%d", width, c.patch_w, c.patch_w, c.image_w);
+    if (width != m->img_w) { m->have_fwd = false; m->have_enc = false; }    // saved activations belong to the old geometry
+    m->img_w = width;
+    m->npa = (c.image_h / c.patch_h) * (width / c.patch_w);
+    m->Sa = m->npa + 1;
+    return KZV_OK;
+}
+
 extern "C" int kzv_check_positions(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "check_positions: model not bound");
     int flag = 0;
@@ -691,22 +713,19 @@ static int ensure_kv_cache(kzv_model* m) {
     for (int i = 0; i < 2; ++i)
         if (hipMalloc((void**)&m->kvc[i], bytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step: KV cache allocation (%zu bytes)", bytes);
     m->kvB = m->B; m->kvT = m->T; m->kv_cur = 0;
+    for (int i = 0; i < 2; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
     return KZV_OK;
 }
 
-extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const unsigned char* d_valid,
-                               int64_t ld_valid, float* d_logits, void* stream) {
-    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_step: model not bound");
-    if (!m->have_enc) return kzv_fail(KZV_E_STATE, "decode_step: call kzv_forward_loss on the images first");
-    if (!d_tokens || !d_posids || !d_valid || !d_logits || t < 0 || t >= m->T) return kzv_fail(KZV_E_ARG, "decode_step: null operand or step outside 0..T-1");
-    KZV_TRY(ensure_kv_cache(m));
-    hipStream_t s = (hipStream_t)stream;
+// one decoder step for the newest token of every sequence; tptr != nullptr: the step index is read from device memory
+// (graph replay), `t` is then only the host's copy for argument checks
+static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const int* tptr, const unsigned char* d_valid,
+                            int64_t ld_valid, float* d_logits, hipStream_t s) {
     const kzv_config& c = m->c;
     const int B = m->B, Hd = m->Hd, Fd = m->Fd, T = m->T;
     float* P = m->P;
     const float eps = c.ln_eps;
     const int CK = m->Ld * 2 * Hd;
-    m->train = false; m->have_fwd = false;      // decoder activations are overwritten: no backward after this
     bf16_t* cache = m->kvc[m->kv_cur];
     const int64_t plane = (int64_t)B * T * Hd;  // one layer's K (or V) cache
     // embeddings of the one new token per sequence (HF modeling_roberta.py:75-122; position ids from the caller)
@@ -718,12 +737,12 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
         const DecLayerP& d = m->dp[i];
         KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, B, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
         KZV_TRY(kzv_attn_decode(a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, cache + (int64_t)(2 * i) * plane, cache + (int64_t)(2 * i + 1) * plane,
-                                (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, t + 1, t, s));
+                                (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr));
         KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, B, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0, 0.f, 0));
         KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, B, Hd, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
         KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd,
-                                (int64_t)m->np * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->np, -1, s));
+                                (int64_t)m->npa * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s));
         KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, B, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0, 0.f, 0));
         KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, B, Hd, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, B, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
@@ -735,6 +754,59 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
     KZV_TRY(kzv_ln_fwd_ex(m->hd_gelu, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, B, Hd, eps, 1, 0, 0.f, 0, s));
     KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, B, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
     KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s));
+    return KZV_OK;
+}
+
+static int decode_step_check(kzv_model* m, const void* a, const void* b, const void* c, const void* d, const char* who) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "%s: model not bound", who);
+    if (!m->have_enc) return kzv_fail(KZV_E_STATE, "%s: call kzv_forward_loss on the images first", who);
+    if (!a || !b || !c || !d) return kzv_fail(KZV_E_ARG, "%s: null operand", who);
+    return KZV_OK;
+}
+
+extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const unsigned char* d_valid,
+                               int64_t ld_valid, float* d_logits, void* stream) {
+    KZV_TRY(decode_step_check(m, d_tokens, d_posids, d_valid, d_logits, "decode_step"));
+    if (t < 0 || t >= m->T) return kzv_fail(KZV_E_ARG, "decode_step: step outside 0..T-1");
+    KZV_TRY(ensure_kv_cache(m));
+    m->train = false; m->have_fwd = false;      // decoder activations are overwritten: no backward after this
+    return decode_step_body(m, d_tokens, d_posids, t, nullptr, d_valid, ld_valid, d_logits, (hipStream_t)stream);
+}
+
+extern "C" int kzv_decode_begin(kzv_model* m, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_begin: model not bound");
+    KZV_TRY(ensure_kv_cache(m));
+    if (hipMemsetAsync(m->d_t, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_begin: memset");
+    return KZV_OK;
+}
+
+extern "C" int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, const int* d_posids, const unsigned char* d_valid, int64_t ld_valid,
+                                     float* d_logits, void* stream) {
+    KZV_TRY(decode_step_check(m, d_tokens, d_posids, d_valid, d_logits, "decode_step_graph"));
+    if (!stream) return kzv_fail(KZV_E_ARG, "decode_step_graph: needs a non-default stream (stream capture)");
+    KZV_TRY(ensure_kv_cache(m));
+    m->train = false; m->have_fwd = false;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = m->kv_cur;
+    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[g], (const void*)(intptr_t)m->npa};
+    bool same = m->dgraph[g] != nullptr && m->dg_ld[g] == ld_valid;
+    for (int i = 0; i < 6 && same; ++i) same = m->dg_key[g][i] == key[i];
+    if (!same) {                               // (re)capture: the step with its index read from m->d_t, then t += 1
+        if (m->dgraph[g]) { (void)hipGraphExecDestroy(m->dgraph[g]); m->dgraph[g] = nullptr; }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step_graph: begin capture");
+        int rc = decode_step_body(m, d_tokens, d_posids, 0, m->d_t, d_valid, ld_valid, d_logits, s);
+        if (rc == KZV_OK) rc = kzv_step_inc(m->d_t, s);
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc != KZV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) return kzv_fail(KZV_E_HIP, "decode_step_graph: end capture (%s)", hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&m->dgraph[g], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { m->dgraph[g] = nullptr; return kzv_fail(KZV_E_HIP, "decode_step_graph: instantiate (%s)", hipGetErrorString(ei)); }
+        for (int i = 0; i < 6; ++i) m->dg_key[g][i] = key[i];
+        m->dg_ld[g] = ld_valid;
+    }
+    if (hipGraphLaunch(m->dgraph[g], s) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step_graph: launch");
     return KZV_OK;
 }
 

@@ -75,6 +75,7 @@ SYMBOLS = {
     "kzv_model_bind": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int]),
     "kzv_model_sync_weights": (C.c_int, [_P, _P]),
     "kzv_forward_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
+    "kzv_set_image_width": (C.c_int, [_P, C.c_int]),
     "kzv_check_positions": (C.c_int, [_P, _P]),
     "kzv_set_active_length": (C.c_int, [_P, C.c_int]),
     "kzv_decode_logits": (C.c_int, [_P, _P, C.c_int, _P, _P]),
@@ -100,6 +101,8 @@ SYMBOLS = {
     "kzv_prof_seen": (C.c_int64, [C.c_int]),
     "kzv_set_cu_reserve": (C.c_int, [C.c_int]),
     "kzv_decode_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "kzv_decode_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kzv_decode_step_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kzv_decode_reorder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kzv_lanczos_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "kzv_preprocess_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,

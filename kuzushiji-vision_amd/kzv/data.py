@@ -9,6 +9,7 @@ Reference behaviour restated (no reference code is imported here):
 """
 from __future__ import annotations
 
+import dataclasses
 import json
 import os
 
@@ -83,16 +84,22 @@ def synthetic_batch(cfg: ModelConfig, batch: int, label_len: int = 128, seed: in
 class SyntheticLineDataset:
     """Map-style dataset with the reference's item dict (src/data/trocr_dataset.py:196-201)."""
 
-    def __init__(self, cfg: ModelConfig, n: int, label_len: int = 128, seed: int = 1):
+    def __init__(self, cfg: ModelConfig, n: int, label_len: int = 128, seed: int = 1, width_buckets=None):
         self.cfg, self.n, self.label_len, self.seed = cfg, n, label_len, seed
         self._chars = None
+        # width buckets (configs[4]): sample i is a crop of width widths[i] (drawn per sample), same height
+        self.widths = None
+        if width_buckets:
+            rng = np.random.default_rng(seed * 7919 + 11)
+            self.widths = [int(w) for w in rng.choice(sorted(width_buckets), size=n)]
 
     def __len__(self) -> int:
         return self.n
 
     def __getitem__(self, i: int):
         import torch
-        px, lab = synthetic_batch(self.cfg, 1, self.label_len, seed=self.seed * 1_000_003 + i)
+        cfg = self.cfg if self.widths is None else dataclasses.replace(self.cfg, image_w=self.widths[i])
+        px, lab = synthetic_batch(cfg, 1, self.label_len, seed=self.seed * 1_000_003 + i)
         if self._chars is None:
             self._chars = synthetic_charset(self.cfg.vocab - len(SPECIAL_TOKENS))
         text = "".join(self._chars[t - 5] for t in lab[0] if t != self.cfg.pad_id)
@@ -144,7 +151,7 @@ class LineCsvDataset:
     the existence filter applies to the resolved path either way)."""
 
     def __init__(self, csv_path, image_root, tokenizer, image_size=(1024, 64), max_length=128, split="train",
-                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, device_preprocess=False, resolve="reference"):
+                 train_ratio=0.8, val_ratio=0.1, test_ratio=0.1, device_preprocess=False, resolve="reference", width_buckets=None):
         import ast
         import pandas as pd
         if abs(train_ratio + val_ratio + test_ratio - 1.0) >= 1e-6:
@@ -173,6 +180,22 @@ class LineCsvDataset:
             self.data = df[b:].reset_index(drop=True)
         else:
             raise ValueError(f"Invalid split: {split}")
+        # width buckets (configs[4]): every crop is resized/padded to (H, its bucket) instead of (H, W); the bucket comes from
+        # the image header (no decode); unreadable files go to the widest bucket (they become all-zero tensors anyway)
+        self.widths = None
+        if width_buckets:
+            from PIL import Image
+            self.widths = []
+            for pth in self.data["full_image_path"]:
+                try:
+                    with Image.open(pth) as im:
+                        w, h = im.size
+                    self.widths.append(bucket_width(w, h, self.image_size[0], width_buckets))
+                except Exception:
+                    self.widths.append(max(width_buckets))
+
+    def _target(self, idx):
+        return self.image_size if self.widths is None else (self.image_size[0], self.widths[idx])
 
     @staticmethod
     def _ids_to_text(ids):
@@ -197,19 +220,21 @@ class LineCsvDataset:
                              return_tensors="pt")
         item = {"labels": enc["input_ids"].squeeze(0), "text": row["text"], "image_path": path}
         if self.device_preprocess:
+            item["target_w"] = self._target(idx)[1]
             # N2: hand the decoded uint8 crop (and its resampling plan) to kzv.preprocess.DevicePreprocessor; an unreadable
             # image becomes None -> an all-zero tensor after the device pass, like the reference's fallback
             from .preprocess import plan_line
             try:
                 u8 = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
-                item["image_u8"], item["plan"] = u8, plan_line(u8.shape[0], u8.shape[1], self.image_size[0], self.image_size[1])
+                th, tw = self._target(idx)
+                item["image_u8"], item["plan"] = u8, plan_line(u8.shape[0], u8.shape[1], th, tw)
             except Exception:
                 item["image_u8"], item["plan"] = None, None
             return item
         try:
-            px = image_to_tensor(resize_with_padding(Image.open(path).convert("RGB"), self.image_size))
+            px = image_to_tensor(resize_with_padding(Image.open(path).convert("RGB"), self._target(idx)))
         except Exception:
-            px = torch.zeros(3, self.image_size[0], self.image_size[1])
+            px = torch.zeros(3, *self._target(idx))
         item["pixel_values"] = px
         return item
 
@@ -217,7 +242,7 @@ class LineCsvDataset:
 def collate_raw(items):
     """collate for device_preprocess datasets: crops stay a list (ragged sizes); see device_batch"""
     import torch
-    return {"image_u8": [i["image_u8"] for i in items], "plan": [i["plan"] for i in items],
+    return {"image_u8": [i["image_u8"] for i in items], "plan": [i["plan"] for i in items], "target_w": items[0].get("target_w"),
             "labels": torch.stack([i["labels"] for i in items]),
             "text": [i["text"] for i in items], "image_path": [i["image_path"] for i in items]}
 
@@ -227,11 +252,12 @@ def device_batch(batch, preprocessor):
     ok = [k for k, im in enumerate(batch["image_u8"]) if im is not None]
     import torch
     n = len(batch["image_u8"])
-    px = torch.zeros(n, 3, preprocessor.target_h, preprocessor.target_w, device=preprocessor.device)
+    tw = batch.get("target_w") or preprocessor.target_w            # width buckets: the batch's own canvas width
+    px = torch.zeros(n, 3, preprocessor.target_h, tw, device=preprocessor.device)
     if ok:
-        got = preprocessor([batch["image_u8"][k] for k in ok], plans=[batch["plan"][k] for k in ok])
+        got = preprocessor([batch["image_u8"][k] for k in ok], plans=[batch["plan"][k] for k in ok], target_w=tw)
         px[torch.tensor(ok, device=px.device)] = got
-    out = {k: v for k, v in batch.items() if k not in ("image_u8", "plan")}
+    out = {k: v for k, v in batch.items() if k not in ("image_u8", "plan", "target_w")}
     out["pixel_values"] = px
     return out
 
@@ -289,13 +315,64 @@ class EpochSampler:
         return iter(idx[self.rank:total:self.world])
 
 
+def bucket_width(in_w: int, in_h: int, target_h: int, buckets) -> int:
+    """Smallest bucket that holds the crop once it is scaled to the target height (ResizeWithPadding keeps the aspect
+    ratio, src/data/trocr_dataset.py:24-53): crops wider than the widest bucket shrink into it like the reference."""
+    need = in_w * target_h / max(1, in_h)
+    for b in sorted(buckets):
+        if need <= b:
+            return b
+    return max(buckets)
+
+
+class BucketBatchSampler:
+    """Batches of same-width-bucket samples (BASELINE.json configs[4]: bucketed 384-1024 px crops, dynamic patch-sequence
+    length): `widths[i]` = bucket of sample i.  Each epoch shuffles inside the buckets (seed + epoch), cuts every bucket into
+    batches (short last batch kept, like the reference's loaders), shuffles the batch order, pads the batch list to a multiple
+    of the world size and deals batches round-robin to the ranks -- so every rank sees the same NUMBER of batches (the gradient
+    all-reduce needs that) while batch shapes may differ between ranks."""
+
+    def __init__(self, widths, batch_size: int, shuffle: bool = True, seed: int = 42, rank: int = 0, world: int = 1):
+        self.widths, self.batch_size, self.shuffle, self.seed, self.rank, self.world, self.epoch = list(widths), batch_size, shuffle, seed, rank, world, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def _batches(self):
+        import torch
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        by = {}
+        for i, w in enumerate(self.widths):
+            by.setdefault(w, []).append(i)
+        out = []
+        for w in sorted(by):
+            idx = by[w]
+            if self.shuffle:
+                idx = [idx[j] for j in torch.randperm(len(idx), generator=g).tolist()]
+            out += [idx[k:k + self.batch_size] for k in range(0, len(idx), self.batch_size)]
+        if self.shuffle:
+            out = [out[j] for j in torch.randperm(len(out), generator=g).tolist()]
+        pad = (-len(out)) % self.world
+        return out + out[:pad]
+
+    def __len__(self) -> int:
+        return len(self._batches()) // self.world
+
+    def __iter__(self):
+        return iter(self._batches()[self.rank::self.world])
+
+
 def make_loader(dataset, batch_size, shuffle, seed=42, rank=0, world=1, drop_last=False, num_workers=0, preprocessor=None):
     """DataLoader over an EpochSampler (per-epoch reshuffle, DistributedSampler-style shard).  drop_last defaults to
     False like the reference's loaders.  `preprocessor` (kzv.preprocess.DevicePreprocessor): for datasets built with
     device_preprocess=True.  The returned loader exposes ``set_epoch``."""
     from torch.utils.data import DataLoader
-    sampler = EpochSampler(len(dataset), shuffle, seed, rank, world)
-    loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate, drop_last=drop_last,
-                        num_workers=num_workers)
+    if getattr(dataset, "widths", None) is not None:     # width buckets: batches of one width each
+        sampler = BucketBatchSampler(dataset.widths, batch_size, shuffle, seed, rank, world)
+        loader = DataLoader(dataset, batch_sampler=sampler, collate_fn=collate, num_workers=num_workers)
+    else:
+        sampler = EpochSampler(len(dataset), shuffle, seed, rank, world)
+        loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate, drop_last=drop_last,
+                            num_workers=num_workers)
     loader.set_epoch = sampler.set_epoch
     return DeviceBatchLoader(loader, preprocessor) if preprocessor is not None else loader

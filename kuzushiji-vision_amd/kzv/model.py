@@ -30,7 +30,7 @@ class TrOCRModel:
 
     def __init__(self, encoder_config: dict[str, Any], decoder_path: str, learning_rate: float = 1e-4,
                  beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8, weight_decay: float = 0,
-                 *, device: str = "cuda", init_seed: int = 42, load_tokenizer: bool = True):
+                 *, device: str = "cuda", init_seed: int = 42, load_tokenizer: bool = True, width_buckets=None):
         import torch
         self.hparams = types.SimpleNamespace(encoder_config=encoder_config, decoder_path=decoder_path,
                                              learning_rate=learning_rate, beta1=beta1, beta2=beta2,
@@ -52,6 +52,14 @@ class TrOCRModel:
         self._step_seed = 0
         self.trim_padding = True
         self._len_cache = (None, 0)
+        # Width buckets (BASELINE.json configs[4]; an extension -- a reference model has one image size): encoder_config's
+        # image_size is the WIDEST crop; batches whose width is one of `width_buckets` (multiples of the patch width, <= it)
+        # run with fewer patch tokens and the position rows of the same (h, w) cells (include/kzv.h: kzv_set_image_width).
+        self.width_buckets = tuple(sorted(int(w) for w in width_buckets)) if width_buckets else None
+        if self.width_buckets:
+            for w in self.width_buckets:
+                if w % self.cfg.patch_w or not (self.cfg.patch_w <= w <= self.cfg.image_w):
+                    raise ValueError(f"width bucket {w} must be a multiple of {self.cfg.patch_w} and <= {self.cfg.image_w}")
 
         lib = L.load()
         c = self.cfg
@@ -188,8 +196,10 @@ class TrOCRModel:
         if pixel_values.dim() != 4 or pixel_values.shape[1] != c.channels:
             raise ValueError(f"pixel_values must be [B,{c.channels},H,W], got {tuple(pixel_values.shape)}")
         _, _, height, width = pixel_values.shape
-        if height != c.image_h or width != c.image_w:   # trocr_model.py:83-86
+        bucket_ok = self.width_buckets is not None and width in self.width_buckets
+        if height != c.image_h or (width != c.image_w and not bucket_ok):   # trocr_model.py:83-86
             raise ValueError(f"Input image size ({height}*{width}) doesn't match model ({c.image_h}*{c.image_w}).")
+        L.check(L.load().kzv_set_image_width(self._h, int(width)), "set_image_width")
         return pixel_values.to(self.device, dtype=torch.float32).contiguous()
 
     def forward_loss(self, pixel_values, labels, want_logits: bool = False, seed: int | None = None):
@@ -278,8 +288,14 @@ class TrOCRModel:
         self.forward_loss(px, ids0, want_logits=False, seed=0)          # encoder + cross K/V (and a first decoder pass)
         state = {"valid": torch.zeros(BB, Lh, dtype=torch.uint8, device=self.device)}   # self-attention keys usable (token != pad)
         posids = torch.empty(BB, dtype=torch.int32, device=self.device)
-        if use_cache:
-            L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")
+        tok_buf = torch.empty(BB, dtype=torch.int64, device=self.device)
+        # the cached step is ~100 small launches: replayed from a hipGraph (kzv_decode_step_graph) unless KZV_DECODE_GRAPH=0;
+        # stream capture needs a non-default stream, so the whole decode loop runs on a side stream
+        graph = use_cache and os.environ.get("KZV_DECODE_GRAPH", "1") != "0"
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device) if graph else cur
+        if graph:
+            side.wait_stream(cur)
 
         def step(t, ids):
             if not use_cache:
@@ -288,27 +304,41 @@ class TrOCRModel:
                 L.check(lib.kzv_set_active_length(self._h, t + 1), "set_active_length")   # later positions are not needed
                 L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
                 return step_logits
-            tok = ids[:, t].contiguous()
-            live = tok != c.pad_id
+            tok_buf.copy_(ids[:, t])
+            live = tok_buf != c.pad_id
             valid = state["valid"]
             valid[:, t] = live.to(torch.uint8)
             # RoBERTa position ids (modeling_roberta.py:142-155): cumsum of non-pad tokens + pad_id; prefixes never hold pads
-            posids.copy_(torch.where(live, torch.full_like(tok, t + 1 + c.pad_id), torch.full_like(tok, c.pad_id)).to(torch.int32))
-            L.check(lib.kzv_decode_step(self._h, tok.data_ptr(), posids.data_ptr(), t, valid.data_ptr(), Lh, step_logits.data_ptr(),
-                                        L.stream_handle()), "decode_step")
+            posids.copy_(torch.where(live, torch.full_like(tok_buf, t + 1 + c.pad_id), torch.full_like(tok_buf, c.pad_id)).to(torch.int32))
+            if graph:
+                L.check(lib.kzv_decode_step_graph(self._h, tok_buf.data_ptr(), posids.data_ptr(), valid.data_ptr(), Lh, step_logits.data_ptr(),
+                                                  L.stream_handle()), "decode_step_graph")
+            else:
+                L.check(lib.kzv_decode_step(self._h, tok_buf.data_ptr(), posids.data_ptr(), t, valid.data_ptr(), Lh, step_logits.data_ptr(),
+                                            L.stream_handle()), "decode_step")
             return step_logits
 
         def reorder(rows, n_keys):
             if use_cache:
                 rows = rows.contiguous()
-                state["valid"] = state["valid"][rows].contiguous()
+                state["valid"].copy_(state["valid"][rows])                # in place: the graph holds this buffer's address
                 L.check(lib.kzv_decode_reorder(self._h, rows.data_ptr(), n_keys, L.stream_handle()), "decode_reorder")
 
         try:
-            if nb == 1:
-                return BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device)
-            return BM.beam_search(step, reorder, B, nb, Lh, c.vocab, c.pad_id, c.bos_id, c.eos_id, self.device,
-                                  early_stopping=early_stopping, length_penalty=length_penalty)
+            with torch.cuda.stream(side):
+                if use_cache:
+                    L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")
+                    L.check(lib.kzv_decode_begin(self._h, L.stream_handle()), "decode_begin")
+                if nb == 1:
+                    out = BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device)
+                else:
+                    out = BM.beam_search(step, reorder, B, nb, Lh, c.vocab, c.pad_id, c.bos_id, c.eos_id, self.device,
+                                         early_stopping=early_stopping, length_penalty=length_penalty)
+            if graph:
+                cur.wait_stream(side)
+                for t_ in (out, step_logits, posids, tok_buf, state["valid"], px):
+                    t_.record_stream(cur)
+            return out
         finally:
             self.training = was
 

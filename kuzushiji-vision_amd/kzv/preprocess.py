@@ -74,12 +74,14 @@ class DevicePreprocessor:
         self.device = torch.device(device)
         self.lut = torch.from_numpy(normalise_lut()).to(self.device)
 
-    def __call__(self, images, plans=None, out=None):
+    def __call__(self, images, plans=None, out=None, target_w=None):
+        """`target_w` overrides the canvas width for this batch (width buckets: every crop of a batch shares one bucket)."""
         import torch
         n = len(images)
         if n == 0:
             raise ValueError("empty batch")
-        plans = plans or [plan_line(im.shape[0], im.shape[1], self.target_h, self.target_w) for im in images]
+        tw = int(target_w) if target_w else self.target_w
+        plans = plans or [plan_line(im.shape[0], im.shape[1], self.target_h, tw) for im in images]
         desc = (L.kzv_line_desc * n)()
         coef_parts, coef_len, src_off, tmp_off, max_tmp = [], 0, 0, 0, 1
         for i, (im, p) in enumerate(zip(images, plans)):
@@ -110,8 +112,8 @@ class DevicePreprocessor:
         d_desc = torch.from_numpy(np.frombuffer(bytes(desc), np.uint8).copy()).to(self.device, non_blocking=True)
         d_tmp = torch.empty(tmp_off + 4, dtype=torch.uint8, device=self.device)
         if out is None:
-            out = torch.empty(n, 3, self.target_h, self.target_w, dtype=torch.float32, device=self.device)
-        L.check(L.load().kzv_preprocess_lines(d_rgb.data_ptr(), d_desc.data_ptr(), d_coef.data_ptr(), n, self.target_h, self.target_w,
+            out = torch.empty(n, 3, self.target_h, tw, dtype=torch.float32, device=self.device)
+        L.check(L.load().kzv_preprocess_lines(d_rgb.data_ptr(), d_desc.data_ptr(), d_coef.data_ptr(), n, self.target_h, tw,
                                                max_tmp, self.lut.data_ptr(), d_tmp.data_ptr(), out.data_ptr(), L.stream_handle()),
                 "preprocess_lines")
         # the staging tensors must outlive the asynchronous kernels: keep them until the next call

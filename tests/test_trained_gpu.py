@@ -145,3 +145,17 @@ def test_validation_and_test_steps_decode_with_beam_search_like_the_reference(tr
             assert got.shape == want.shape and np.array_equal(got, want), (es, uc)
     full = m.tokenizer.batch_decode(want, skip_special_tokens=True)
     assert [O.calculate_cer(p, t) for p, t in zip(full, tgt)] == [0.0] * len(tgt)
+
+
+def test_graph_replayed_decode_step_equals_the_eager_step(trained, monkeypatch):
+    """kzv_decode_step_graph (device-side step index, one hipGraph per cache copy) against the eager kzv_decode_step: same
+    tokens for greedy and beam-4, on the fitted crops and on flat-logit crops, twice in a row (graph reuse across calls)."""
+    g, cfg, sd, data, m = trained
+    px = torch.from_numpy(np.concatenate([data["fit"][0], data["unseen"][0]]))
+    for beams in (1, 4):
+        outs = {}
+        for mode in ("0", "1", "1"):
+            monkeypatch.setenv("KZV_DECODE_GRAPH", mode)
+            outs.setdefault(mode, []).append(m.generate(px, max_length=20, num_beams=beams, early_stopping=False).cpu().numpy())
+        assert np.array_equal(outs["1"][0], outs["1"][1])
+        assert outs["0"][0].shape == outs["1"][0].shape and np.array_equal(outs["0"][0], outs["1"][0]), beams
