@@ -172,6 +172,10 @@ typedef struct kzv_gemm_nt_args {
     float drop_p; uint32_t drop_key;  /* KZV_EPI_RESID dropout on (acc+bias); p=0 -> off */
 } kzv_gemm_nt_args;
 int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream);
+/* kzv_gemm_nt picks a kernel by shape: the LDS-staged 128x128 / 256x256 kernels, except for M <= rows_max_m (default 0 =
+ * never; KZV_ROWS_MAX_M), which takes the few-rows kernel the generation step (kzv_decode_step*) uses internally for its
+ * M = batch GEMMs (one wave per 16x64 tile).  The per-op tests raise the threshold to check that kernel through this entry. */
+int kzv_set_rows_max_m(int n);
 
 /* OUT[N,K] (+)= P[Mtok,N]^T . Q[Mtok,K]   (weight gradient; fp32 atomics over token splits) */
 typedef struct kzv_gemm_tn_args {

@@ -1,11 +1,9 @@
 // N1: KV-cached decoder step: one new token per sequence attends over cached keys / values.
 //
 // Replaces, for generation only, the per-step work of HF RobertaSelfAttention / RobertaCrossAttention with `use_cache=True`
-// (modeling_roberta.py:186-326) as driven by `decoder.generate` (src/models/trocr_model.py:306-316).  One wave per
-// (sequence, head): every lane scores up to NU keys (NU = 3: <= 192 keys; NU = 5: <= 320, the reference's default 1024x64
-// columns give 256 cross-attention keys) against the 64-dim query in fp32, softmax across the wave,
-// then lane d accumulates output dimension d over the keys (128-B coalesced V rows).  The self-attention variant also
-// appends this step's key and value to the cache.  Work per step is tiny (B*heads waves); the step is launch-bound.
+// (modeling_roberta.py:186-326) as driven by `decoder.generate` (src/models/trocr_model.py:306-316).  One workgroup per
+// (sequence, head), fp32 scores and softmax (see attn_decode_kernel); the self-attention variant also appends this step's key
+// and value to the cache.  The reference's default 1024x64 columns give 256 cross-attention keys.
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
@@ -24,27 +22,33 @@ struct DecAttnP {
     const int* tptr;                              // non-null: the step index t lives in device memory (graph replay): nkeys = t + 1, append_at = t
 };
 
+// One 256-thread workgroup per (sequence, head).  Phase 1: thread j scores key j (+256) against the query (the key row is
+// one 128-B line: 8 x 16-B loads per thread), softmax across the workgroup.  Phase 2: a wave-instruction reads 4 value rows
+// (lane = 4 dims of one of 4 keys: 512 contiguous-per-row bytes), wave w takes keys 16 i + 4 w + (lane >> 4); partial sums
+// are folded by two shuffles and one pass through LDS.  NU = keys per thread in phase 1 (1: <= 256 keys, 2: <= 512).
 template <int NU>
-__global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
-    __shared__ float prob[64 * NU];
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
+    __shared__ float prob[256 * NU];
     __shared__ float qs[64];
-    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, lane = threadIdx.x;
+    __shared__ float red[8];
+    __shared__ float part[4][64];
+    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     bf16_t* Kb = p.K + (int64_t)b * p.kb + h * 64;
     bf16_t* Vb = p.V + (int64_t)b * p.kb + h * 64;
     const int tdev = p.tptr ? *p.tptr : 0;
-    const int nkeys = p.tptr ? min(tdev + 1, 64 * NU) : p.nkeys;
-    const int append_at = p.tptr ? min(tdev, 64 * NU - 1) : p.append_at;
-    if (append_at >= 0) {                         // lane d copies dimension d of the new key and value into the cache
-        Kb[(int64_t)append_at * p.kj + lane] = p.knew[(int64_t)b * p.ldnew + h * 64 + lane];
-        Vb[(int64_t)append_at * p.kj + lane] = p.vnew[(int64_t)b * p.ldnew + h * 64 + lane];
+    const int nkeys = p.tptr ? min(tdev + 1, 256 * NU) : p.nkeys;
+    const int append_at = p.tptr ? min(tdev, 256 * NU - 1) : p.append_at;
+    if (append_at >= 0 && tid < 64) {             // thread d copies dimension d of the new key and value into the cache
+        Kb[(int64_t)append_at * p.kj + tid] = p.knew[(int64_t)b * p.ldnew + h * 64 + tid];
+        Vb[(int64_t)append_at * p.kj + tid] = p.vnew[(int64_t)b * p.ldnew + h * 64 + tid];
     }
-    qs[lane] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + lane]) * p.scale;
-    __syncthreads();                              // cache row + query visible to the whole wave
+    if (tid < 64) qs[tid] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + tid]) * p.scale;
+    __syncthreads();                              // cache row + query visible to the whole workgroup
     float sc[NU];
     float mx = -INFINITY;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int j = lane + 64 * u;
+        const int j = tid + 256 * u;
         sc[u] = -INFINITY;
         if (j < nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) {
             const bf16x8* kr = (const bf16x8*)(Kb + (int64_t)j * p.kj);
@@ -60,18 +64,34 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const DecAttnP p) {
         mx = fmaxf(mx, sc[u]);
     }
     mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const bool dead = mx == -INFINITY;            // no usable key (a finished, all-pad row): output zeros
     float sum = 0.f;
 #pragma unroll
     for (int u = 0; u < NU; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; }
     sum = wave_sum(sum);
-    const float inv = dead ? 0.f : 1.f / sum;
+    if (lane == 0) red[4 + w] = sum;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) prob[lane + 64 * u] = sc[u] * inv;
+    for (int u = 0; u < NU; ++u) prob[tid + 256 * u] = sc[u];
     __syncthreads();
-    float o = 0.f;
-    for (int j = 0; j < nkeys; ++j) o += prob[j] * bf2f(Vb[(int64_t)j * p.kj + lane]);
-    p.out[(int64_t)b * p.ldo + h * 64 + lane] = f2bf(o);
+    sum = red[4] + red[5] + red[6] + red[7];
+    const float inv = dead ? 0.f : 1.f / sum;
+    // phase 2: out[d] = inv * sum_j prob[j] * V[j][d]
+    const int ksub = lane >> 4, dq = lane & 15;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int j = 4 * w + ksub; j < nkeys; j += 16) {
+        const uint2 v = *(const uint2*)(Vb + (int64_t)j * p.kj + dq * 4);
+        const float pj = prob[j];
+        o0 += pj * bf2f((bf16_t)(v.x & 0xffffu)); o1 += pj * bf2f((bf16_t)(v.x >> 16));
+        o2 += pj * bf2f((bf16_t)(v.y & 0xffffu)); o3 += pj * bf2f((bf16_t)(v.y >> 16));
+    }
+    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64); o3 += __shfl_xor(o3, 16, 64);
+    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);
+    if (ksub == 0) { part[w][dq * 4 + 0] = o0; part[w][dq * 4 + 1] = o1; part[w][dq * 4 + 2] = o2; part[w][dq * 4 + 3] = o3; }
+    __syncthreads();
+    if (tid < 64) p.out[(int64_t)b * p.ldo + h * 64 + tid] = f2bf((part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * inv);
 }
 
 // beam re-ordering: dst[l][b][j][:] = src[l][idx[b]][j][:] for j < len (16-byte chunks)
@@ -99,10 +119,11 @@ int kzv_step_inc(int* d_t, hipStream_t s) {
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
                     int append_at, hipStream_t s, const int* tptr) {
-    if (nkeys < 1 || nkeys > 320) return kzv_fail(KZV_E_ARG, "attn_decode: 1..320 keys");
+    if (nkeys < 1 || nkeys > 512) return kzv_fail(KZV_E_ARG, "attn_decode: 1..512 keys");
+    if (kj % 8) return kzv_fail(KZV_E_ARG, "attn_decode: key rows must be 16-byte aligned");
     DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr};
-    if (nkeys <= 192) hipLaunchKernelGGL(attn_decode_kernel<3>, dim3(B * heads), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(attn_decode_kernel<5>, dim3(B * heads), dim3(64), 0, s, p);
+    if (nkeys <= 256) hipLaunchKernelGGL(attn_decode_kernel<1>, dim3(B * heads), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_decode_kernel<2>, dim3(B * heads), dim3(256), 0, s, p);
     return kzv_check_launch("attn_decode");
 }
 

@@ -412,6 +412,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     // the workgroup-wide LDS epilogue of gemm_nt256.hip (512-B / 1-KiB row segments).
     static int use_p = -1;
     if (use_p < 0) { const char* e = getenv("KZV_NT256P"); use_p = e ? atoi(e) : 1; }
+    if (kzv_rows_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");      // M <= 1024: the generation step's GEMMs
     const bool two_store = epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32;
     if (use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
     if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");

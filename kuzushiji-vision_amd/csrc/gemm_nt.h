@@ -61,3 +61,8 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
 int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);
 // gemm_nt256p.hip (persistent variant of the same schedule): same contract.
 int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s);
+// gemm_rows.hip (few rows: one wave per 16x64 tile, operands straight from L2): same contract.  Taken inside a KzvRowsScope
+// (the generation step, model.cpp) for M <= 4096, elsewhere only below kzv_set_rows_max_m (default 0: never), so that the
+// training step and its parity tests keep running the tiled kernels at every size.
+int kzv_rows_launch(const NtParams& p, int epilogue, hipStream_t s);
+struct KzvRowsScope { KzvRowsScope(); ~KzvRowsScope(); };

@@ -11,6 +11,7 @@
 #include "kzv_host.h"
 #include "kzv_kernels.h"
 #include "../../include/kzv.h"
+#include "gemm_nt.h"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -726,6 +727,7 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
     float* P = m->P;
     const float eps = c.ln_eps;
     const int CK = m->Ld * 2 * Hd;
+    KzvRowsScope rows_scope;                     // M = B rows: every GEMM of the step takes the few-rows kernel (gemm_rows.hip)
     bf16_t* cache = m->kvc[m->kv_cur];
     const int64_t plane = (int64_t)B * T * Hd;  // one layer's K (or V) cache
     // embeddings of the one new token per sequence (HF modeling_roberta.py:75-122; position ids from the caller)

@@ -88,6 +88,7 @@ SYMBOLS = {
     "kzv_clip_and_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(kzv_opt_step), _P]),
     "kzv_lerp_params": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "kzv_gemm_nt": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
+    "kzv_set_rows_max_m": (C.c_int, [C.c_int]),
     "kzv_gemm_tn": (C.c_int, [C.POINTER(kzv_gemm_tn_args), _P]),
     "kzv_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "kzv_layernorm_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),

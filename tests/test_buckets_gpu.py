@@ -55,7 +55,7 @@ def _bucket_case(cfg, tmp_path, widths, B, Lh, seed):
             if k == "encoder.position_embeddings":
                 full = got.reshape(1, cfg.enc_seq, cfg.enc_hidden)
                 rest = np.delete(full, rows, axis=1)
-                assert np.abs(rest).max() == 0.0            # rows of cells outside the narrow grid get no gradient
+                assert rest.size == 0 or np.abs(rest).max() == 0.0            # rows of cells outside the narrow grid get no gradient
                 got = full[:, rows]
             got = got.reshape(v.shape)
             assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, (w, k)

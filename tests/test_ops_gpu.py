@@ -32,8 +32,17 @@ def _gemm_nt(lib, A, B, epi, bias=None, n_store=None, resid=None, aux=None, drop
     return out
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 132, 128), (483, 384, 192), (1000, 4300, 256), (77, 64, 768)])
-def test_gemm_nt_epilogues(lib, M, N, K):
+@pytest.fixture(params=["rows", "tiled"])
+def small_gemm_kernel(request, lib):
+    """threshold 1024: the few-rows kernel of the generation step (gemm_rows.hip); threshold 0 (the default): the same
+    shapes through the LDS-staged 128x128 kernel the training step uses for the decoder's GEMMs."""
+    L.check(lib.kzv_set_rows_max_m(1024 if request.param == "rows" else 0), "rows_max_m")
+    yield request.param
+    L.check(lib.kzv_set_rows_max_m(0), "rows_max_m")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 132, 128), (483, 384, 192), (1000, 4300, 256), (77, 64, 768), (256, 768, 256), (1, 64, 64)])
+def test_gemm_nt_epilogues(lib, small_gemm_kernel, M, N, K):
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K, device=DEV).bfloat16()
     B = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
@@ -91,7 +100,7 @@ def test_gemm_nt_large_shapes_take_the_256x256_kernel(lib, M, N, K, nv):
         assert torch.equal(_gemm_nt(lib, A, B, L.EPI_F32, bias, n_store=N), first)
 
 
-def test_gemm_nt_padded_columns_are_zero(lib):
+def test_gemm_nt_padded_columns_are_zero(lib, small_gemm_kernel):
     A = torch.randn(130, 64, device=DEV).bfloat16()
     B = torch.randn(157, 64, device=DEV).bfloat16()
     bias = torch.randn(157, device=DEV)

@@ -11,9 +11,9 @@ with tempfile.TemporaryDirectory() as tmp:
     m = TrOCRModel(cfg.encoder_config_dict(), build_decoder_dir(os.path.join(tmp, "d"), cfg), load_tokenizer=False)
 px = torch.from_numpy(synthetic_batch(cfg, 256, 128, seed=1)[0]).cuda()
 m.eval()
-for graph in ("0", "1"):
+for graph in (os.environ.get("DEC_GRAPHS", "0,1").split(",")):
     os.environ["KZV_DECODE_GRAPH"] = graph
-    for beams in (1, 4):
+    for beams in [int(b) for b in os.environ.get("DEC_BEAMS", "1,4").split(",")]:
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             out = m.generate(px, max_length=128, num_beams=beams, early_stopping=False)
