@@ -44,6 +44,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
     }
     if (tid < 64) qs[tid] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + tid]) * p.scale;
     __syncthreads();                              // cache row + query visible to the whole workgroup
+    // phase-2 operands first: the value rows this lane will weight (addresses do not depend on the probabilities), so that keys
+    // and values share one memory round trip
+    const int ksub = lane >> 4, dq = lane & 15;
+    constexpr int VI = 16 * NU;
+    uint2 vv[VI];
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int j = 4 * w + ksub + 16 * i;
+        vv[i] = j < nkeys ? *(const uint2*)(Vb + (int64_t)j * p.kj + dq * 4) : make_uint2(0, 0);
+    }
     float sc[NU];
     float mx = -INFINITY;
 #pragma unroll
@@ -79,13 +89,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
     sum = red[4] + red[5] + red[6] + red[7];
     const float inv = dead ? 0.f : 1.f / sum;
     // phase 2: out[d] = inv * sum_j prob[j] * V[j][d]
-    const int ksub = lane >> 4, dq = lane & 15;
     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int j = 4 * w + ksub; j < nkeys; j += 16) {
-        const uint2 v = *(const uint2*)(Vb + (int64_t)j * p.kj + dq * 4);
-        const float pj = prob[j];
-        o0 += pj * bf2f((bf16_t)(v.x & 0xffffu)); o1 += pj * bf2f((bf16_t)(v.x >> 16));
-        o2 += pj * bf2f((bf16_t)(v.y & 0xffffu)); o3 += pj * bf2f((bf16_t)(v.y >> 16));
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int j = 4 * w + ksub + 16 * i;
+        const float pj = j < nkeys ? prob[j] : 0.f;
+        o0 += pj * bf2f((bf16_t)(vv[i].x & 0xffffu)); o1 += pj * bf2f((bf16_t)(vv[i].x >> 16));
+        o2 += pj * bf2f((bf16_t)(vv[i].y & 0xffffu)); o3 += pj * bf2f((bf16_t)(vv[i].y >> 16));
     }
     o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64); o3 += __shfl_xor(o3, 16, 64);
     o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);

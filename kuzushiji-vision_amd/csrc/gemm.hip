@@ -220,14 +220,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const NtParams p)
 // Reduction index inside a 32-token MFMA step is permuted (element j of lane group g <-> token
 // 16*(j>>2) + 4g + (j&3)); both operands use the same permutation so the sum is unchanged, and the two
 // groups of a 32-lane half then read 8 consecutive rows -> the XOR swizzle below is conflict-free.
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+__device__ __forceinline__ void gemm_tn_body(const TnParams& p, const int bid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int wn = w >> 1, wk = w & 1;     // wave tile: n in [wn*64,+64), k in [wk*64,+64)
     const int tilesN = (p.N + 127) / 128, tilesK = (p.K + 127) / 128;
     const int per = tilesN * tilesK;
-    const int id = xcd_remap(blockIdx.x, per * p.splits);
+    const int id = xcd_remap(bid, per * p.splits);
     const int split = id / per, rem = id - split * per;
     const int tnb = rem / tilesK, tkb = rem - tnb * tilesK;
     const int t_begin = split * p.chunk;
@@ -386,6 +386,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) { gemm_tn_body(p, blockIdx.x); }
+
+// Grouped launch: several independent weight gradients (e.g. the six of one decoder layer, 4..12 tiles of 128x128 each)
+// share ONE grid, so the 256 CUs x 2 resident workgroups are filled in a single round instead of six part-filled ones.
+constexpr int TN_GROUP_MAX = 8;
+struct TnGroup { TnParams p[TN_GROUP_MAX]; int start[TN_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(const TnGroup g) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    gemm_tn_body(g.p[i], (int)blockIdx.x - g.start[i]);
+}
+
 }  // namespace
 
 extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
@@ -440,36 +453,90 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     return kzv_check_launch("gemm_nt");
 }
 
-extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
+static int tn_fill(const kzv_gemm_tn_args* a, TnParams& p) {
     if (!a || !a->P || !a->Q || !a->OUT) return kzv_fail(KZV_E_ARG, "gemm_tn: null operand");
     if (a->Mtok <= 0 || a->N <= 0 || a->K <= 0) return kzv_fail(KZV_E_ARG, "gemm_tn: empty shape");
     if (a->N % 8 || a->K % 8 || a->ldp % 8 || a->ldq % 8 || a->ldo % 4) return kzv_fail(KZV_E_ARG, "gemm_tn: N,K,ldp,ldq %8, ldo %4");
     if (((uintptr_t)a->P | (uintptr_t)a->Q | (uintptr_t)a->OUT) & 15) return kzv_fail(KZV_E_ARG, "gemm_tn: operands must be 16-byte aligned");
-    TnParams p;
     p.P = (const bf16_t*)a->P; p.Q = (const bf16_t*)a->Q; p.OUT = a->OUT; p.zero16 = kzv_zero_page();
     if (!p.zero16) return kzv_fail(KZV_E_HIP, "gemm_tn: zero page unavailable");
     p.ldp = a->ldp; p.ldq = a->ldq; p.ldo = a->ldo;
     p.Mtok = a->Mtok; p.N = a->N; p.K = a->K; p.n_store = a->n_store > 0 ? a->n_store : a->N;
     p.dbias = a->dbias;
-    KzvProfScope prof(1, 2.0 * a->Mtok * p.n_store * a->K, (hipStream_t)stream);
-    if (kzv_tn256_launch(p, (hipStream_t)stream)) return kzv_check_launch("gemm_tn");     // >= 24 tiles of 256x256: eight-phase kernel
-    const int tiles = ((a->N + 127) / 128) * ((a->K + 127) / 128);
-    const int tok_tiles = (a->Mtok + 63) / 64;
-    // Token splits: fill the 512 resident slots (256 CUs x 2 workgroups) in ONE round without overshooting
-    // it, and keep >= 16 reduction steps per workgroup so the 64 float atomics per lane of the epilogue
-    // (issue-bound, and contended when many splits hit one small output) stay a small share.
-    static int target = -1, min_steps = -1;
-    if (target < 0) { const char* e = getenv("KZV_TN_BLOCKS"); target = e ? atoi(e) : 512; }
+    return KZV_OK;
+}
+// Token splits of one problem given the workgroup budget `target` it may fill: ONE resident round without overshooting
+// it, and >= min_steps reduction steps per workgroup so the 64 float atomics per lane of the epilogue (issue-bound, and
+// contended when many splits hit one small output) stay a small share.  Returns the workgroup count.
+static int tn_plan(TnParams& p, int target) {
+    static int min_steps = -1;
     if (min_steps < 0) { const char* e = getenv("KZV_TN_MINSTEPS"); min_steps = e ? atoi(e) : 16; }
+    const int tiles = ((p.N + 127) / 128) * ((p.K + 127) / 128);
+    const int tok_tiles = (p.Mtok + 63) / 64;
     int splits = target / tiles;
     if (splits > tok_tiles / min_steps) splits = tok_tiles / min_steps;
     if (splits > tok_tiles) splits = tok_tiles;
     if (splits < 1) splits = 1;
-    int chunk_tiles = (tok_tiles + splits - 1) / splits;
+    const int chunk_tiles = (tok_tiles + splits - 1) / splits;
     splits = (tok_tiles + chunk_tiles - 1) / chunk_tiles;
     p.splits = splits; p.chunk = chunk_tiles * 64;
+    return tiles * splits;
+}
+static int tn_target() {
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("KZV_TN_BLOCKS"); target = e ? atoi(e) : 512; }
+    return target;
+}
+
+extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
+    TnParams p;
+    const int rc = tn_fill(a, p);
+    if (rc != KZV_OK) return rc;
+    KzvProfScope prof(1, 2.0 * a->Mtok * p.n_store * a->K, (hipStream_t)stream);
+    if (kzv_tn256_launch(p, (hipStream_t)stream)) return kzv_check_launch("gemm_tn");     // >= 24 tiles of 256x256: eight-phase kernel
+    const int blocks = tn_plan(p, tn_target());
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS); attr_done = true; }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), NT_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(blocks), dim3(256), NT_LDS, (hipStream_t)stream, p);
     return kzv_check_launch("gemm_tn");
+}
+
+// n independent weight gradients in one grid (model.cpp: the six of a decoder layer; head; cross-K/V + projection).
+// Problems the 256x256 kernel would take are launched on their own.  The workgroup budget (one resident round) is shared
+// in proportion to the tile counts.
+int kzv_gemm_tn_group(const kzv_gemm_tn_args* a, int n, hipStream_t s) {
+    if (n <= 0) return KZV_OK;
+    if (n == 1 || n > TN_GROUP_MAX) {
+        for (int i = 0; i < n; ++i) { const int rc = kzv_gemm_tn(a + i, s); if (rc != KZV_OK) return rc; }
+        return KZV_OK;
+    }
+    TnGroup g;
+    g.n = 0;
+    int tiles_total = 0;
+    double work = 0;
+    for (int i = 0; i < n; ++i) {
+        TnParams p;
+        const int rc = tn_fill(a + i, p);
+        if (rc != KZV_OK) return rc;
+        const int t256 = ((p.n_store + 255) / 256) * ((p.K + 255) / 256);
+        if (t256 >= 24) { const int r2 = kzv_gemm_tn(a + i, s); if (r2 != KZV_OK) return r2; continue; }   // the eight-phase kernel's shapes
+        g.p[g.n++] = p;
+        tiles_total += ((p.N + 127) / 128) * ((p.K + 127) / 128);
+        work += 2.0 * p.Mtok * p.n_store * p.K;
+    }
+    if (g.n == 0) return KZV_OK;
+    KzvProfScope prof(1, work, s);
+    int blocks = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const int tiles = ((g.p[i].N + 127) / 128) * ((g.p[i].K + 127) / 128);
+        int share = (int)((int64_t)tn_target() * tiles / tiles_total);
+        if (share < tiles) share = tiles;
+        g.start[i] = blocks;
+        blocks += tn_plan(g.p[i], share);
+    }
+    g.start[g.n] = blocks;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS); attr_done = true; }
+    hipLaunchKernelGGL(gemm_tn_group_kernel, dim3(blocks), dim3(256), NT_LDS, s, g);
+    return kzv_check_launch("gemm_tn_group");
 }

@@ -37,6 +37,10 @@ struct KzvCastDesc {         // one 2-D fp32 weight -> bf16 copy (+ optional tra
 };
 int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s);
 
+// gemm.hip: n independent weight gradients in one grid
+struct kzv_gemm_tn_args;
+int kzv_gemm_tn_group(const kzv_gemm_tn_args* a, int n, hipStream_t s);
+
 // optim.hip
 int kzv_sqnorm(const float* g, int64_t n, float* out1, float* scratch, hipStream_t s);
 

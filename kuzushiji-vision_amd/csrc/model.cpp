@@ -70,6 +70,8 @@ struct kzv_model {
     float *dx_e, *dx_d, *dsum_d;
     bf16_t *dy_e2;           // second dy_e (overlap mode 2: the fc2 weight gradient still reads dy_e while LayerNorm-2 backward writes its output)
     bf16_t *dy_e, *dbig_e, *dh_e, *dqkv_e, *dctx_e, *dpatch, *denc_out, *denc, *dckv, *dy_d, *dbig_d, *dqkv_d, *dctx_d, *dq_d, *dhln;
+    bf16_t *dy_d2, *dy_d3;   // the decoder's three "dropout(linear)" gradients of a layer stay alive until its grouped weight-gradient launch
+    std::vector<kzv_gemm_tn_args> wbatch;
     // weight-gradient GEMMs run on an internal side stream so they overlap the input-gradient chain on the
     // caller's stream (their tails and epilogues fill each other's idle workgroup slots)
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr; hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -243,6 +245,7 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
     m->denc = m->has_proj ? b.take<bf16_t>(Mp * Hd) : m->denc_out;
     m->dckv = b.take<bf16_t>(Mp * CK);
     m->dx_d = b.take<float>(Md * Hd); m->dsum_d = b.take<float>(Md * Hd);
+    m->dy_d2 = b.take<bf16_t>(Md * Hd); m->dy_d3 = b.take<bf16_t>(Md * Hd);
     m->dy_d = b.take<bf16_t>(Md * Hd); m->dbig_d = b.take<bf16_t>(Md * Fd); m->dqkv_d = b.take<bf16_t>(Md * 3 * Hd);
     m->dctx_d = b.take<bf16_t>(Md * Hd); m->dq_d = b.take<bf16_t>(Md * Hd); m->dhln = b.take<bf16_t>(Md * Hd);
     (void)weights_end;
@@ -276,6 +279,17 @@ int wgrad(const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW
     return kzv_gemm_tn(&a, s);
 }
 
+// Small weight gradients of one backward stage are collected and launched as ONE grid (kzv_gemm_tn_group): each alone
+// fills a fraction of the chip (4..12 tiles of 128x128).  Only without the side stream (which has its own overlap).
+int wgrad_batch(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok,
+                int N, int K, int n_store, float* dbias);
+int wgrad_flush(kzv_model* m, hipStream_t s) {
+    if (m->wbatch.empty()) return KZV_OK;
+    const int rc = kzv_gemm_tn_group(m->wbatch.data(), (int)m->wbatch.size(), s);
+    m->wbatch.clear();
+    return rc;
+}
+
 // buffer classes whose last side-stream reader must finish before the main stream overwrites them
 enum { CLS_DY = 0, CLS_DBIG = 1, CLS_DQKV = 2, CLS_MISC = 3 };
 
@@ -288,6 +302,15 @@ int wgrad_async(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t 
     if (rc != KZV_OK) return rc;
     if (hipEventRecord(m->ev_done[cls], m->side) != hipSuccess) return kzv_fail(KZV_E_HIP, "wgrad_async: record");
     m->pending[cls] = true;
+    return KZV_OK;
+}
+int wgrad_batch(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok,
+                int N, int K, int n_store, float* dbias) {
+    if (m->use_side) return wgrad_async(m, cls, s, dY, ldp, X, ldq, dW, Mtok, N, K, n_store, dbias);
+    kzv_gemm_tn_args a;
+    memset(&a, 0, sizeof(a));
+    a.P = dY; a.ldp = ldp; a.Q = X; a.ldq = ldq; a.OUT = dW; a.ldo = K; a.Mtok = Mtok; a.N = N; a.K = K; a.n_store = n_store; a.dbias = dbias;
+    m->wbatch.push_back(a);
     return KZV_OK;
 }
 int wait_cls(kzv_model* m, int cls, hipStream_t s) {
@@ -415,14 +438,16 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     const int Mp = B * m->npa, Md = B * T, Me = B * m->Sa;
     float* P = m->P; float* G = m->G;
     const int CK = m->Ld * 2 * Hd;
+    m->wbatch.clear();
     // ---- CE -> LM head ------------------------------------------------------------------------------
-    KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, G + m->hbias));
+    KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, G + m->hbias));
     KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
     KZV_TRY(kzv_ln_bwd_ex(m->dhln, 0, m->hd_gelu, m->hd_st, P + m->hln_w, m->dsum_d, 0, G + m->hln_w, G + m->hln_b, Md, Hd, 1, 0, 0.f, 0, s));
     KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
     const bf16_t* x_last_h = m->Ld ? m->da[m->Ld - 1].x3h : m->xd0h;
-    KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, nullptr));
+    KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, nullptr));
     KZV_TRY(gemm(m->dy_d, Hd, m->w_hd, true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_F32, s));
+    KZV_TRY(wgrad_flush(m, s));          // LM head (tied word embedding) + head dense: before dy_d is rewritten
     // ---- decoder layers, last to first -----------------------------------------------------------------
     for (int i = m->Ld - 1; i >= 0; --i) {
         DecAct& a = m->da[i];
@@ -433,46 +458,50 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
         KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s3, a.st3, P + d.ln3w, m->dsum_d, 0, G + d.ln3w, G + d.ln3b, Md, Hd, 1, 0, 0.f, 0, s,
                               m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 4)));
-        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
+        KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
         KZV_TRY(wait_cls(m, CLS_DBIG, s));
         KZV_TRY(gemm(m->dy_d, Hd, m->w_dfc2[i], true, Md, Fd, Hd, Fd, nullptr, m->dbig_d, Fd, KZV_EPI_DGELU, s, nullptr, a.pre, Fd));
-        KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
+        KZV_TRY(wgrad_batch(m, CLS_DBIG, s, m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
         KZV_TRY(gemm(m->dbig_d, Fd, m->w_dfc1[i], true, Md, Hd, Fd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // cross-attention block: x2 = LN(s2), s2 = x1 + drop(o(CA(q(x1), kv(enc))))
         KZV_TRY(wait_cls(m, CLS_DY, s));
+        bf16_t* dy2 = m->use_side ? m->dy_d : m->dy_d2;      // grouped launch: the three dy of a layer stay alive until its end
+        bf16_t* dy3 = m->use_side ? m->dy_d : m->dy_d3;
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s2, a.st2, P + d.ln2w, m->dsum_d, 0, G + d.ln2w, G + d.ln2b, Md, Hd, 1, 0, 0.f, 0, s,
-                              m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 3)));
-        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
+                              dy2, dp(m, c.dec_hidden_dropout), key(m, site + 3)));
+        KZV_TRY(wgrad_batch(m, CLS_DY, s, dy2, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
         KZV_TRY(wait_cls(m, CLS_MISC, s));   // dq_d (and, first layer, dlogits' reader) before the cross-attention backward rewrites dq_d
-        KZV_TRY(gemm(m->dy_d, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
+        KZV_TRY(gemm(dy2, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
                      m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->npa,
                      dp(m, c.dec_attn_dropout), key(m, site + 2), s));
-        KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
+        KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
         KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // self-attention block: x1 = LN(s1), s1 = x + drop(o(SA(qkv(x))))
         KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s1, a.st1, P + d.ln1w, m->dsum_d, 0, G + d.ln1w, G + d.ln1b, Md, Hd, 1, 0, 0.f, 0, s,
-                              m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 1)));
-        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_d, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
+                              dy3, dp(m, c.dec_hidden_dropout), key(m, site + 1)));
+        KZV_TRY(wgrad_batch(m, CLS_DY, s, dy3, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
         KZV_TRY(wait_cls(m, CLS_DQKV, s));
-        KZV_TRY(gemm(m->dy_d, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
+        KZV_TRY(gemm(dy3, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
                      m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
-        KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
+        KZV_TRY(wgrad_batch(m, CLS_DQKV, s, m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
         KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+        KZV_TRY(wgrad_flush(m, s));      // the six weight gradients of this layer in one grid
     }
     // ---- decoder embeddings: x0 = drop(LN(word + type + pos)) ---------------------------------------------
     KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, m->emb_sum, m->emb_st, P + m->eln_w, m->dsum_d, 0, G + m->eln_w, G + m->eln_b, Md, Hd, 1, 0,
                           dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
     KZV_TRY(kzv_embed_scatter_bwd(m->dsum_d, m->labels, m->L, m->posids, G + m->word, G + m->dtype, G + m->dpos, B, T, Hd, c.pad_id, s));
     // ---- cross K/V projection of all layers, encoder_decoder_proj, final encoder LN ---------------------------
-    KZV_TRY(wgrad_async(m, CLS_MISC, s, m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, G + m->ckv_b));
+    KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dckv, CK, m->proj_out, Hd, G + m->ckv_w, Mp, CK, Hd, CK, G + m->ckv_b));
     KZV_TRY(gemm(m->dckv, CK, m->w_ckv, true, Mp, Hd, CK, Hd, nullptr, m->denc, Hd, KZV_EPI_BF16, s));
     if (m->has_proj) {
-        KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, G + m->proj_b));
+        KZV_TRY(wgrad_batch(m, CLS_DQKV, s, m->denc, Hd, m->enc_out, He, G + m->proj_w, Mp, Hd, He, Hd, G + m->proj_b));
         KZV_TRY(gemm(m->denc, Hd, m->w_proj, true, Mp, He, Hd, He, nullptr, m->denc_out, He, KZV_EPI_BF16, s));
     }
+    KZV_TRY(wgrad_flush(m, s));          // cross-attention K/V of all layers + encoder_decoder_proj
     // also emits the masked bf16 copy the top ViT layer's fc2 backward starts from
     KZV_TRY(wait_cls(m, CLS_DY, s));
     KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Sa, 1, 0.f, 0, s,
