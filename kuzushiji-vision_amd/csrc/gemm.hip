@@ -418,6 +418,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.M = a->M; p.N = a->N; p.K = a->K; p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
     kzv_drop_params(a->drop_p, &p.drop_thr16, &p.drop_inv_keep);
     p.drop_key = a->drop_key;
+    p.strip = kzv_nt_strip();
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
     // large shapes: 256x256 eight-phase kernels.  The persistent one wins wherever its per-wave drain is light (one

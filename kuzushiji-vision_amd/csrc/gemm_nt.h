@@ -10,6 +10,7 @@ struct NtParams {
     int64_t lda, ldb, ldc, ldr, ldaux;
     int M, N, K, n_valid;
     unsigned drop_thr16; float drop_inv_keep; unsigned drop_key;
+    int strip;          // tile-walk strip width of the 256x256 kernels (nt_tile_coords)
 };
 
 // One thread finishes 4 consecutive columns n0..n0+3 of output row m: v = accumulator + bias on entry;
@@ -56,6 +57,22 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
         nt_st((uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0), make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])));
     }
 }
+
+// Tile walk of the 256x256 kernels: column STRIPS of `strip` tile columns, row-major inside a strip.  The 32 CUs of an XCD
+// run 32 consecutive tile ids at a time; in plain row-major order those span every B (weight) column panel of a wide
+// output (N = 2304: 9 panels = 3.5 MB, N = 3072: 4.7 MB next to the A row panels in a 4 MiB L2 -> the weights are
+// re-streamed from the Infinity Cache every round); inside a strip they span `strip` panels (3 x 393 KB at K = 768)
+// and ~32/strip A row panels, which stream through once per strip.  strip <= 0 or >= tilesN: plain row-major.
+__device__ __forceinline__ void nt_tile_coords(int id, int tilesM, int tilesN, int strip, int& tm, int& tn) {
+    if (strip <= 0 || strip >= tilesN) { tm = id / tilesN; tn = id - tm * tilesN; return; }
+    const int per = tilesM * strip;
+    const int st = id / per;
+    const int rem = id - st * per;
+    const int w = min(strip, tilesN - st * strip);       // the last strip may be narrower (its ids are the tail of the range)
+    tm = rem / w;
+    tn = st * strip + (rem - tm * w);
+}
+int kzv_nt_strip();      // KZV_NT_STRIP (default 3)
 
 // gemm_nt256.hip: returns 1 when it took the launch, 0 when the shape is left to the 128x128 kernel.
 int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);

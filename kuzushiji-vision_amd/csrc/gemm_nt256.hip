@@ -59,7 +59,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const NtParams p) {
     const int wr = w >> 2, wc = w & 3;
     const int tilesN = (p.N + 255) / 256, tilesM = (p.M + 255) / 256;
     const int id = xcd_remap(blockIdx.x, tilesM * tilesN);
-    const int tm = id / tilesN, tn = id - tm * tilesN;
+    int tm, tn;
+    nt_tile_coords(id, tilesM, tilesN, p.strip, tm, tn);
 
     // ---- LDS-DMA sources: wave w fills 1-KiB pieces w and w+8 of every half-tile (8 rows x 128 B each) ----
     // Rows beyond M / columns beyond n_valid are clamped to a valid row: their products are never stored.

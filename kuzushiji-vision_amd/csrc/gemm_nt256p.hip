@@ -58,7 +58,7 @@ struct TileSrc {            // where the next half-tiles of one half index (h) c
 };
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN) {
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN, const int strip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,8 +74,9 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
         const int id = seq * G + vblk;
         s.valid = id < tiles;
         const int idc = s.valid ? id : 0;
-        const int tm = __builtin_amdgcn_readfirstlane(idc / tilesN);
-        const int tn = idc - tm * tilesN;
+        int tm, tn;
+        nt_tile_coords(idc, tiles / tilesN, tilesN, strip, tm, tn);
+        tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
         s.a = (const char*)(p.A + (int64_t)tm * 256 * p.lda);
         s.b = (const char*)p.B;
         int ln = lane;
@@ -280,11 +281,15 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
 #define KZV_STAMP() do {} while (0)
 #endif
     KZV_STAMP();
+#ifdef KZV_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int seq = 0; ; ++seq) {
         const int id = seq * G + vblk;
         if (id >= tiles) break;
-        const int tm = __builtin_amdgcn_readfirstlane(id / tilesN);
-        const int tn = id - tm * tilesN;
+        int tm, tn;
+        nt_tile_coords(id, tiles / tilesN, tilesN, strip, tm, tn);
+        tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
         // nk is even (launcher): every tile starts on ring buffer 0, so the two K-tile bodies alternate statically
         // (selecting the body by a run-time parity made hipcc spill half the accumulators)
         for (int kt = 0; kt < nk; kt += 2) {
@@ -302,9 +307,19 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
         zero_acc();
         KZV_STAMP();
     }
+#ifdef KZV_STAMPS
+    if (stp) { stp[14] = clk0; stp[15] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
 }
 
+}  // namespace
+int kzv_nt_strip() {
+    static int v = -1000;
+    if (v == -1000) { const char* e = getenv("KZV_NT_STRIP"); v = e ? atoi(e) : 3; }
+    return v;
+}
+namespace {
 int nt256p_min_tiles() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("KZV_NT256P_MIN_TILES"); v = e ? atoi(e) : 384; }
@@ -332,7 +347,7 @@ int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s) {
     case E: {                                                                                                       \
         static bool attr_done = false;                                                                              \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<E>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN);         \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<E>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN, kzv_nt_strip());         \
     } break;
     switch (epilogue) {
         KZV_NT256P_CASE(KZV_EPI_BF16) KZV_NT256P_CASE(KZV_EPI_F32) KZV_NT256P_CASE(KZV_EPI_GELU)

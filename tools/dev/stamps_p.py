@@ -17,17 +17,24 @@ for (M, N, K) in [(41216, 2304, 768), (41216, 768, 768), (41216, 768, 3072)]:
         rc = lib.kzv_gemm_nt(C.byref(a), 0, torch.cuda.current_stream().cuda_stream)
         assert rc == 0
     torch.cuda.synchronize()
-    t = st.cpu().view(256, 16)
-    t0 = int(t[:, 0][t[:, 0] > 0].min())
     import numpy as np
-    starts = (t[:, 0].numpy() - t0) / 100.0
-    ends = np.array([(max(r.tolist()) - t0) / 100.0 for r in t])
-    ntl = np.array([(sum(1 for x in r.tolist() if x) - 1) // 2 for r in t])
-    print(f"== {M}x{N}x{K}: start min/med/max {starts.min():.1f}/{np.median(starts):.1f}/{starts.max():.1f} us; end min/med/max {ends.min():.1f}/{np.median(ends):.1f}/{ends.max():.1f} us; tiles/block {ntl.min()}..{ntl.max()}")
-    r = t[0].tolist(); print("   block 0:", " ".join(f"{(x - t0) / 100:.1f}" for x in r if x))
-    k = int(ends.argmax()); r = t[k].tolist(); print(f"   block {k} (last):", " ".join(f"{(x - t0) / 100:.1f}" for x in r if x))
+    def report(tag):
+        t = st.cpu().view(256, 16)
+        clk = t[:, 14:16].numpy().copy(); t = t.clone(); t[:, 14:] = 0
+        t0 = int(t[:, 0][t[:, 0] > 0].min())
+        starts = (t[:, 0].numpy() - t0) / 100.0
+        ends = np.array([(max(r.tolist()) - t0) / 100.0 for r in t])
+        dur = np.array([(max(r.tolist()) - r[0].item()) / 100.0 for r in t])
+        ghz = (clk[:, 1] - clk[:, 0]) / np.maximum(dur, 1e-9) / 1e3
+        print(f"== {tag} {M}x{N}x{K}: end min/med/max {ends.min():.1f}/{np.median(ends):.1f}/{ends.max():.1f} us; in-kernel clock med {np.median(ghz):.2f} GHz (min {ghz.min():.2f}, max {ghz.max():.2f})")
+        r = t[0].tolist(); print("   block 0:", " ".join(f"{(x - t0) / 100:.1f}" for x in r if x))
+    report("cold")
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20): lib.kzv_gemm_nt(C.byref(a), 0, torch.cuda.current_stream().cuda_stream)
-    e1.record(); torch.cuda.synchronize()
-    print(f"   event-timed: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
+    for _ in range(200): lib.kzv_gemm_nt(C.byref(a), 0, torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    st.zero_()
+    lib.kzv_gemm_nt(C.byref(a), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    print(f"   event-timed: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us per launch (200 back to back)")
+    report("hot ")
