@@ -103,6 +103,13 @@ int kzv_set_active_length(kzv_model* m, int t_active);
  * pos only depends on ids[:, :pos+1].  Invalidates the saved activations (no backward afterwards). */
 int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos, float* d_logits, void* stream);
 
+/* Encoder only (ViTEncoder.forward + encoder_decoder_proj + the cross-attention K/V of every decoder layer) for n_images
+ * crops [n_images, C, H, W], n_images dividing the bound batch: the bound batch counts DECODER rows, and beam search runs
+ * batch / n_images beams per image that all attend to that image's K/V (HF expands encoder_hidden_states per beam,
+ * trocr_model.py:306-316 -> generate; the values are identical, so they are computed and stored once).  Only
+ * kzv_decode_step* may follow (kzv_decode_logits / kzv_forward_loss need one image per row). */
+int kzv_encode_images(kzv_model* m, const float* d_pixel_values, int n_images, void* stream);
+
 /* KV-cached generation step (what `decoder.generate(use_cache=True)` does per token, trocr_model.py:306-316): feeds ONE
  * token per sequence -- d_tokens [B] at decoder index t, with RoBERTa position ids d_posids [B] (t + 1 + pad_id for a live
  * sequence, pad_id for padding) -- through the decoder against the self-attention keys / values cached by steps 0..t-1
@@ -152,6 +159,10 @@ typedef struct kzv_opt_step {
 int kzv_grad_sqnorm(const float* d_grads, int64_t n, float* d_out1, float* d_scratch, void* stream);
 int kzv_clip_and_step(float* d_params, float* d_z, float* d_v, const float* d_grads, int64_t n,
                       const float* d_sqnorm, const kzv_opt_step* s, void* stream);
+/* The same step with the EMA of the parameters (src/callbacks/ema.py:51-58: shadow = decay * shadow + (1 - decay) * param
+ * after every batch) updated in the same pass from the freshly stepped parameters; d_ema NULL = no EMA. */
+int kzv_clip_and_step_ema(float* d_params, float* d_z, float* d_v, const float* d_grads, int64_t n,
+                          const float* d_sqnorm, const kzv_opt_step* s, float* d_ema, float ema_decay, void* stream);
 /* optimizer.eval()/train() parameter swap (trocr_model.py:423-451): p <- p + w*(z - p) */
 int kzv_lerp_params(float* d_params, const float* d_z, int64_t n, float w, void* stream);
 

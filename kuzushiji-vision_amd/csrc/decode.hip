@@ -20,6 +20,7 @@ struct DecAttnP {
     int nkeys, append_at, heads;                  // append_at >= 0: write knew/vnew at key index append_at first
     float scale;
     const int* tptr;                              // non-null: the step index t lives in device memory (graph replay): nkeys = t + 1, append_at = t
+    int group;                                    // keys / values of sequence b live at batch index b / group (beams sharing one image's cross-attention K/V)
 };
 
 // One 256-thread workgroup per (sequence, head).  Phase 1: thread j scores key j (+256) against the query (the key row is
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
     __shared__ float red[8];
     __shared__ float part[4][64];
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    bf16_t* Kb = p.K + (int64_t)b * p.kb + h * 64;
-    bf16_t* Vb = p.V + (int64_t)b * p.kb + h * 64;
+    bf16_t* Kb = p.K + (int64_t)(b / p.group) * p.kb + h * 64;
+    bf16_t* Vb = p.V + (int64_t)(b / p.group) * p.kb + h * 64;
     const int tdev = p.tptr ? *p.tptr : 0;
     const int nkeys = p.tptr ? min(tdev + 1, 256 * NU) : p.nkeys;
     const int append_at = p.tptr ? min(tdev, 256 * NU - 1) : p.append_at;
@@ -128,10 +129,11 @@ int kzv_step_inc(int* d_t, hipStream_t s) {
 // tptr != nullptr: self-attention of graph-replayed step `*tptr` (nkeys = the cache capacity, which picks the kernel)
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
-                    int append_at, hipStream_t s, const int* tptr) {
+                    int append_at, hipStream_t s, const int* tptr, int group) {
     if (nkeys < 1 || nkeys > 512) return kzv_fail(KZV_E_ARG, "attn_decode: 1..512 keys");
+    if (group < 1 || (append_at >= 0 && group != 1)) return kzv_fail(KZV_E_ARG, "attn_decode: shared keys cannot be appended to");
     if (kj % 8) return kzv_fail(KZV_E_ARG, "attn_decode: key rows must be 16-byte aligned");
-    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr};
+    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr, group};
     if (nkeys <= 256) hipLaunchKernelGGL(attn_decode_kernel<1>, dim3(B * heads), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(attn_decode_kernel<2>, dim3(B * heads), dim3(256), 0, s, p);
     return kzv_check_launch("attn_decode");

@@ -53,6 +53,7 @@ struct kzv_model {
     // bound state
     float* P = nullptr; float* G = nullptr; char* ws = nullptr; int64_t ws_bytes = 0;
     int B = 0, L = 0, T = 0, Ta = 0;
+    int Be = 0;              // images the encoder states / cross-attention K/V currently hold (B after kzv_forward_loss; fewer after kzv_encode_images)
     bool bound = false, have_fwd = false, have_enc = false, train = false;
     uint64_t seed = 0;
     const int64_t* labels = nullptr;
@@ -327,24 +328,25 @@ int join_side(kzv_model* m, hipStream_t s) {
 
 int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, const bf16_t* K, const bf16_t* V, int64_t ldkv,
          bf16_t* O, int64_t ldo, float* LSE, const bf16_t* dO, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int heads, int Sq, int Sk,
-         float drop_p, uint32_t drop_key, hipStream_t s) {
+         float drop_p, uint32_t drop_key, hipStream_t s, int batch = 0) {
     kzv_attn_args a;
     memset(&a, 0, sizeof(a));
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = ldo;
     a.ids = m->labels; a.ld_ids = m->L; a.pad_id = m->c.pad_id;
-    a.B = m->B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.mode = mode; a.drop_p = drop_p; a.drop_key = drop_key;
+    a.B = batch > 0 ? batch : m->B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.mode = mode; a.drop_p = drop_p; a.drop_key = drop_key;
     return bwd ? kzv_attn_bwd(&a, s) : kzv_attn_fwd(&a, s);
 }
 
 // ================================================================================================ forward
 int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss, float* d_logits, hipStream_t s,
-            bool run_encoder = true, int logits_pos = -1) {
+            bool run_encoder = true, int logits_pos = -1, int enc_batch = 0, bool run_decoder = true) {
     const kzv_config& c = m->c;
     // T = ACTIVE decoder length (kzv_set_active_length): positions >= T hold only padding in every sample, are
     // masked as keys and carry no loss, so the decoder runs on the packed [B, T] prefix (rows b*T + t).
-    const int B = m->B, T = m->Ta, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
-    const int Me = B * m->Sa, Mp = B * m->npa, Md = B * T;
+    const int T = m->Ta, He = m->He, Fe = m->Fe, Hd = m->Hd, Fd = m->Fd;
+    int B = enc_batch > 0 ? enc_batch : m->B;          // encoder batch (kzv_encode_images: fewer images than decoder rows)
+    const int Me = B * m->Sa, Mp = B * m->npa;
     float* P = m->P;
     const float eps = c.ln_eps;
     m->labels = labels;
@@ -365,7 +367,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         KZV_TRY(kzv_ln_fwd_ex(a.x_in, P + e.ln1w, P + e.ln1b, a.ln1, nullptr, a.st1, Me, He, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.ln1, He, m->w_eqkv[i], false, Me, 3 * He, He, 3 * He, P + e.qkvb, a.qkv, 3 * He, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, false, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, nullptr, nullptr, nullptr, nullptr,
-                     c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+                     c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, B));
         KZV_TRY(gemm(a.ctx, He, m->w_eo[i], false, Me, He, He, He, P + e.ob, a.x_mid, He, KZV_EPI_RESID, s, a.x_in, nullptr, 0,
                      dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
         KZV_TRY(kzv_ln_fwd_ex(a.x_mid, P + e.ln2w, P + e.ln2b, a.ln2, nullptr, a.st2, Me, He, eps, 1, 0, 0.f, 0, s));
@@ -379,8 +381,12 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         KZV_TRY(gemm(m->enc_out, He, m->w_proj, false, Mp, Hd, He, Hd, P + m->proj_b, m->proj_out, Hd, KZV_EPI_BF16, s));
     // cross-attention K/V of every decoder layer in one GEMM
     KZV_TRY(gemm(m->proj_out, Hd, m->w_ckv, false, Mp, CK, Hd, CK, P + m->ckv_b, m->crosskv, CK, KZV_EPI_BF16, s));
-    m->have_enc = true;
+    m->have_enc = true; m->Be = B;
     }   // run_encoder
+    if (!run_decoder) return KZV_OK;
+    B = m->B;
+    if (m->Be != B) return kzv_fail(KZV_E_STATE, "forward: the encoder states hold %d images, the decoder batch is %d (kzv_encode_images is for kzv_decode_step only)", m->Be, B);
+    const int Md = B * T;
     // ---- decoder embeddings (HF modeling_roberta.py:75-122,142-155) --------------------------------------
     KZV_TRY(kzv_dec_prepare(labels, B, m->L, T, c.pad_id, c.max_pos, m->posids, m->count, m->err, s));
     KZV_TRY(kzv_embed_gather(labels, m->L, m->posids, P + m->word, P + m->dtype, P + m->dpos, m->emb_sum, B, T, Hd, s));
@@ -718,6 +724,14 @@ extern "C" int kzv_check_positions(kzv_model* m, void* stream) {
     return KZV_OK;
 }
 
+extern "C" int kzv_encode_images(kzv_model* m, const float* d_pixel_values, int n_images, void* stream) {
+    if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "encode_images: model not bound");
+    if (!d_pixel_values || n_images < 1 || n_images > m->B || m->B % n_images)
+        return kzv_fail(KZV_E_ARG, "encode_images: 1 <= n_images <= bound batch %d, which must be a multiple of it", m->B);
+    m->train = false; m->seed = 0; m->have_fwd = false;
+    return forward(m, d_pixel_values, nullptr, nullptr, nullptr, (hipStream_t)stream, true, -1, n_images, false);
+}
+
 extern "C" int kzv_set_active_length(kzv_model* m, int t_active) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "set_active_length: model not bound");
     if (t_active < 1 || t_active > m->T) return kzv_fail(KZV_E_ARG, "set_active_length: must be in 1..%d", m->T);
@@ -773,7 +787,7 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
         KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, B, Hd, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
         KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd,
-                                (int64_t)m->npa * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s));
+                                (int64_t)m->npa * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s, nullptr, B / m->Be));
         KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, B, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0, 0.f, 0));
         KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, B, Hd, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, B, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
@@ -790,8 +804,9 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
 
 static int decode_step_check(kzv_model* m, const void* a, const void* b, const void* c, const void* d, const char* who) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "%s: model not bound", who);
-    if (!m->have_enc) return kzv_fail(KZV_E_STATE, "%s: call kzv_forward_loss on the images first", who);
+    if (!m->have_enc) return kzv_fail(KZV_E_STATE, "%s: call kzv_forward_loss / kzv_encode_images on the images first", who);
     if (!a || !b || !c || !d) return kzv_fail(KZV_E_ARG, "%s: null operand", who);
+    if (m->Be < 1 || m->B % m->Be) return kzv_fail(KZV_E_STATE, "%s: %d decoder rows are not a multiple of the %d encoded images", who, m->B, m->Be);
     return KZV_OK;
 }
 
@@ -819,7 +834,7 @@ extern "C" int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, cons
     m->train = false; m->have_fwd = false;
     hipStream_t s = (hipStream_t)stream;
     const int g = m->kv_cur;
-    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[g], (const void*)(intptr_t)m->npa};
+    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[g], (const void*)(intptr_t)(m->npa * 4096 + m->Be)};
     bool same = m->dgraph[g] != nullptr && m->dg_ld[g] == ld_valid;
     for (int i = 0; i < 6 && same; ++i) same = m->dg_key[g][i] == key[i];
     if (!same) {                               // (re)capture: the step with its index read from m->d_t, then t += 1

@@ -77,6 +77,7 @@ SYMBOLS = {
     "kzv_forward_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, _P]),
     "kzv_set_image_width": (C.c_int, [_P, C.c_int]),
     "kzv_check_positions": (C.c_int, [_P, _P]),
+    "kzv_encode_images": (C.c_int, [_P, _P, C.c_int, _P]),
     "kzv_set_active_length": (C.c_int, [_P, C.c_int]),
     "kzv_decode_logits": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "kzv_zero_grads": (C.c_int, [_P, _P]),
@@ -86,6 +87,7 @@ SYMBOLS = {
     "kzv_backward": (C.c_int, [_P, _P]),
     "kzv_grad_sqnorm": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "kzv_clip_and_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(kzv_opt_step), _P]),
+    "kzv_clip_and_step_ema": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P, C.POINTER(kzv_opt_step), _P, C.c_float, _P]),
     "kzv_lerp_params": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "kzv_gemm_nt": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
     "kzv_set_rows_max_m": (C.c_int, [C.c_int]),

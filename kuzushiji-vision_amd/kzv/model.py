@@ -279,13 +279,19 @@ class TrOCRModel:
         was = self.training
         self.training = False
         nb = max(1, int(num_beams))
-        if nb > 1:
-            px = px.repeat_interleave(nb, dim=0)
         BB = B * nb
+        share = use_cache and nb > 1          # beams share their image's encoder states / cross-attention K/V (kzv_encode_images)
+        if nb > 1 and not share:
+            px = px.repeat_interleave(nb, dim=0)
         ids0 = torch.full((BB, Lh), c.pad_id, dtype=torch.int64, device=self.device)
         ids0[:, 0] = c.bos_id
         step_logits = torch.empty(BB, c.vocab, dtype=torch.float32, device=self.device)
-        self.forward_loss(px, ids0, want_logits=False, seed=0)          # encoder + cross K/V (and a first decoder pass)
+        if share:
+            self._bind(BB, Lh)
+            self._keep = (px, ids0)
+            L.check(lib.kzv_encode_images(self._h, px.data_ptr(), B, L.stream_handle()), "encode_images")
+        else:
+            self.forward_loss(px, ids0, want_logits=False, seed=0)          # encoder + cross K/V (and a first decoder pass)
         state = {"valid": torch.zeros(BB, Lh, dtype=torch.uint8, device=self.device)}   # self-attention keys usable (token != pad)
         posids = torch.empty(BB, dtype=torch.int32, device=self.device)
         tok_buf = torch.empty(BB, dtype=torch.int64, device=self.device)

@@ -35,6 +35,7 @@ class RAdamScheduleFree:
         self.v = torch.zeros_like(flat)
         self._sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self._scratch = torch.zeros(2048, dtype=torch.float32, device=flat.device)
+        self._ema = None            # (shadow tensor, decay): kzv.ema.EMACallback attaches itself so that step() fuses its update
         self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
 
     # ---- per-step scalars (identical to oracle.RAdamScheduleFreeState.next_scalars) ----
@@ -72,9 +73,15 @@ class RAdamScheduleFree:
         s = L.kzv_opt_step(lr_t=lr, ckp1=ckp1, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
                            weight_decay=self.weight_decay, bias_correction2=bc2, adaptive=int(adaptive),
                            max_grad_norm=max_grad_norm, grad_scale=grad_scale, one_minus_beta2=1.0 - self.beta2)
-        L.check(lib.kzv_clip_and_step(m.flat_params.data_ptr(), self.z.data_ptr(), self.v.data_ptr(),
-                                      m.flat_grads.data_ptr(), n, self._sq.data_ptr(), C.byref(s), st), "clip_and_step")
+        ema, decay = self._ema if self._ema is not None else (None, 0.0)
+        L.check(lib.kzv_clip_and_step_ema(m.flat_params.data_ptr(), self.z.data_ptr(), self.v.data_ptr(),
+                                          m.flat_grads.data_ptr(), n, self._sq.data_ptr(), C.byref(s), L.ptr(ema), decay, st), "clip_and_step")
+        self.ema_fused_steps = getattr(self, "ema_fused_steps", 0) + (1 if ema is not None else 0)
         m.sync_weights()
+
+    def attach_ema(self, shadow, decay: float):
+        """EMA shadow updated inside the optimizer kernel (the parameters are in registers there): kzv.ema.EMACallback."""
+        self._ema = (shadow, float(decay)) if shadow is not None else None
 
     def grad_norm(self) -> float:
         """Total L2 norm of the gradient the last step clipped, i.e. AFTER the data-parallel mean (grad_scale applied)."""

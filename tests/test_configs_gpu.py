@@ -160,9 +160,11 @@ def test_two_rank_stepper_on_one_gpu(tmp_path):
     for k in mine:
         if k.endswith("key.bias"):      # exactly-zero true gradient: Adam normalises float-atomic noise there
             continue
-        scale = np.abs(mine[k]).max() + 1e-12
-        assert np.abs(mine[k] - theirs[k]).max() < 2e-5 * scale + 1e-7, k
-        moved = max(moved, float(np.abs(mine[k] - init[k].reshape(mine[k].shape)).max()))
+        step_k = float(np.abs(mine[k] - init[k].reshape(mine[k].shape)).max())       # how far the optimizer moved this tensor
+        # the two runs differ by float-atomic summation order in the gradients; Adam's normalisation turns that into a
+        # small fraction of the update (elements whose gradient sits near the rounding floor): compare against the update
+        assert np.abs(mine[k] - theirs[k]).max() < 0.02 * step_k + 1e-7, (k, step_k)
+        moved = max(moved, step_k)
     assert moved > 1e-3                   # the steps after the optimizer's silent phase moved the parameters
 
 
