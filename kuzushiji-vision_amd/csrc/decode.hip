@@ -23,14 +23,15 @@ struct DecAttnP {
     int group;                                    // keys / values of sequence b live at batch index b / group (beams sharing one image's cross-attention K/V)
 };
 
-// One 256-thread workgroup per (sequence, head).  Phase 1: thread j scores key j (+256) against the query (the key row is
-// one 128-B line: 8 x 16-B loads per thread), softmax across the workgroup.  Phase 2: a wave-instruction reads 4 value rows
-// (lane = 4 dims of one of 4 keys: 512 contiguous-per-row bytes), wave w takes keys 16 i + 4 w + (lane >> 4); partial sums
-// are folded by two shuffles and one pass through LDS.  NU = keys per thread in phase 1 (1: <= 256 keys, 2: <= 512).
+// One 256-thread workgroup per (sequence, head).  Every global access is a wave-instruction over 8 key (or value) rows x
+// 128 contiguous bytes: lane = (row r = lane >> 3, 16-byte chunk c = lane & 7), wave w of iteration i owns key 32 i + 8 w + r.
+// Phase 1: each lane multiplies its chunk of the key by the matching 8 query dimensions (held in registers), three shuffles
+// sum the 8 chunks of a key, the scores meet in LDS and are soft-maxed by one thread per key.  Phase 2: the same lanes weight
+// their chunk of the value row (requested up front, next to the keys: one memory round trip for both), three shuffles sum
+// the 8 rows of a wave-instruction, the four waves' partial outputs meet in LDS.  NU: 256 NU keys at most.
 template <int NU>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
     __shared__ float prob[256 * NU];
-    __shared__ float qs[64];
     __shared__ float red[8];
     __shared__ float part[4][64];
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -39,41 +40,43 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
     const int tdev = p.tptr ? *p.tptr : 0;
     const int nkeys = p.tptr ? min(tdev + 1, 256 * NU) : p.nkeys;
     const int append_at = p.tptr ? min(tdev, 256 * NU - 1) : p.append_at;
-    if (append_at >= 0 && tid < 64) {             // thread d copies dimension d of the new key and value into the cache
-        Kb[(int64_t)append_at * p.kj + tid] = p.knew[(int64_t)b * p.ldnew + h * 64 + tid];
-        Vb[(int64_t)append_at * p.kj + tid] = p.vnew[(int64_t)b * p.ldnew + h * 64 + tid];
+    if (append_at >= 0) {                         // thread d copies dimension d of the new key and value into the cache
+        if (tid < 64) {
+            Kb[(int64_t)append_at * p.kj + tid] = p.knew[(int64_t)b * p.ldnew + h * 64 + tid];
+            Vb[(int64_t)append_at * p.kj + tid] = p.vnew[(int64_t)b * p.ldnew + h * 64 + tid];
+        }
+        __syncthreads();                          // the appended row is read back below by other waves of this workgroup
     }
-    if (tid < 64) qs[tid] = bf2f(p.q[(int64_t)b * p.ldq + h * 64 + tid]) * p.scale;
-    __syncthreads();                              // cache row + query visible to the whole workgroup
-    // phase-2 operands first: the value rows this lane will weight (addresses do not depend on the probabilities), so that keys
-    // and values share one memory round trip
-    const int ksub = lane >> 4, dq = lane & 15;
-    constexpr int VI = 16 * NU;
-    uint2 vv[VI];
+    const int r = lane >> 3, c = lane & 7;
+    constexpr int NI = 8 * NU;
+    bf16x8 kk[NI], vv[NI];
 #pragma unroll
-    for (int i = 0; i < VI; ++i) {
-        const int j = 4 * w + ksub + 16 * i;
-        vv[i] = j < nkeys ? *(const uint2*)(Vb + (int64_t)j * p.kj + dq * 4) : make_uint2(0, 0);
+    for (int i = 0; i < NI; ++i) {
+        const int j = 32 * i + 8 * w + r;
+        const bool in = j < nkeys;
+        kk[i] = in ? *(const bf16x8*)(Kb + (int64_t)j * p.kj + c * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        vv[i] = in ? *(const bf16x8*)(Vb + (int64_t)j * p.kj + c * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
+    float qc[8];
+    {
+        const bf16x8 q8 = *(const bf16x8*)(p.q + (int64_t)b * p.ldq + h * 64 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qc[e] = bf2f((bf16_t)q8[e]) * p.scale;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = 32 * i + 8 * w + r;
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += qc[e] * bf2f((bf16_t)kk[i][e]);
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+        if (c == 0) prob[j] = (j < nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) ? a : -INFINITY;
+    }
+    __syncthreads();
     float sc[NU];
     float mx = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int j = tid + 256 * u;
-        sc[u] = -INFINITY;
-        if (j < nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) {
-            const bf16x8* kr = (const bf16x8*)(Kb + (int64_t)j * p.kj);
-            float a = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const bf16x8 kv = kr[c];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a += qs[c * 8 + e] * bf2f((bf16_t)kv[e]);
-            }
-            sc[u] = a;
-        }
-        mx = fmaxf(mx, sc[u]);
-    }
+    for (int u = 0; u < NU; ++u) { sc[u] = prob[tid + 256 * u]; mx = fmaxf(mx, sc[u]); }
     mx = wave_max(mx);
     if (lane == 0) red[w] = mx;
     __syncthreads();
@@ -81,26 +84,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
     const bool dead = mx == -INFINITY;            // no usable key (a finished, all-pad row): output zeros
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; }
+    for (int u = 0; u < NU; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; prob[tid + 256 * u] = sc[u]; }
     sum = wave_sum(sum);
     if (lane == 0) red[4 + w] = sum;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) prob[tid + 256 * u] = sc[u];
     __syncthreads();
     sum = red[4] + red[5] + red[6] + red[7];
     const float inv = dead ? 0.f : 1.f / sum;
     // phase 2: out[d] = inv * sum_j prob[j] * V[j][d]
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < VI; ++i) {
-        const int j = 4 * w + ksub + 16 * i;
-        const float pj = j < nkeys ? prob[j] : 0.f;
-        o0 += pj * bf2f((bf16_t)(vv[i].x & 0xffffu)); o1 += pj * bf2f((bf16_t)(vv[i].x >> 16));
-        o2 += pj * bf2f((bf16_t)(vv[i].y & 0xffffu)); o3 += pj * bf2f((bf16_t)(vv[i].y >> 16));
+    for (int i = 0; i < NI; ++i) {
+        const float pj = prob[32 * i + 8 * w + r];           // 0 for keys beyond nkeys (their scores were -inf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += pj * bf2f((bf16_t)vv[i][e]);
     }
-    o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64); o3 += __shfl_xor(o3, 16, 64);
-    o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);
-    if (ksub == 0) { part[w][dq * 4 + 0] = o0; part[w][dq * 4 + 1] = o1; part[w][dq * 4 + 2] = o2; part[w][dq * 4 + 3] = o3; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 8, 64); o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[w][c * 8 + e] = o[e];
+    }
     __syncthreads();
     if (tid < 64) p.out[(int64_t)b * p.ldo + h * 64 + tid] = f2bf((part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * inv);
 }

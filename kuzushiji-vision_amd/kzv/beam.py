@@ -66,8 +66,15 @@ def beam_search(step, reorder, batch: int, num_beams: int, max_len: int, vocab: 
     cur = prompt
     while True:
         logp = torch.log_softmax(step(cur - 1, run_seq.view(B * nb, max_len)).float(), dim=-1)
-        acc = (logp.view(B, nb, vocab) + run_sc.unsqueeze(-1)).view(B, nb * vocab)
-        top_lp, top_ix = acc.topk(K, dim=1)
+        acc = logp.view(B, nb, vocab) + run_sc.unsqueeze(-1)
+        # top K of the nb * vocab continuations in two stages (the K best overall are among each beam's K best): one
+        # single-block top-k per beam row instead of a multi-pass radix select over nb * vocab entries per batch element
+        if vocab > 4 * K:
+            blp, bix = acc.topk(K, dim=2)                                  # [B, nb, K]
+            top_lp, sel = blp.reshape(B, nb * K).topk(K, dim=1)
+            top_ix = (bix + (torch.arange(nb, device=device) * vocab).view(1, nb, 1)).reshape(B, nb * K).gather(1, sel)
+        else:
+            top_lp, top_ix = acc.view(B, nb * vocab).topk(K, dim=1)
         src, tok = top_ix // vocab, top_ix % vocab
         cand = run_seq.gather(1, src.unsqueeze(-1).expand(B, K, max_len)).clone()
         cand[:, :, cur] = tok

@@ -230,7 +230,7 @@ def test_beam_and_greedy_bookkeeping_equal_hf_generate():
 
     from kzv import beam as BM
     warnings.filterwarnings("ignore")
-    V, B, H = 13, 4, 32
+    V, B, H = 41, 4, 32          # > 4 * 2 * num_beams: the two-stage top-k of kzv/beam.py is the path under test
     cfg = RobertaConfig(vocab_size=V, hidden_size=H, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
                         max_position_embeddings=40, pad_token_id=1, bos_token_id=2, eos_token_id=3, is_decoder=True,
                         add_cross_attention=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
