@@ -1,9 +1,9 @@
 // N1: KV-cached decoder step: one new token per sequence attends over cached keys / values.
 //
 // Replaces, for generation only, the per-step work of HF RobertaSelfAttention / RobertaCrossAttention with `use_cache=True`
-// (modeling_roberta.py:186-326) as driven by `decoder.generate` (src/models/trocr_model.py:306-316).  One workgroup per
-// (sequence, head), fp32 scores and softmax (see attn_decode_kernel); the self-attention variant also appends this step's key
-// and value to the cache.  The reference's default 1024x64 columns give 256 cross-attention keys.
+// (modeling_roberta.py:186-326) as driven by `decoder.generate` (src/models/trocr_model.py:306-316).  One wave per
+// (sequence, head), fp32 scores and softmax in registers (see attn_decode_kernel); the self-attention variant also appends this
+// step's key and value to the cache.  The reference's default 1024x64 columns give 256 cross-attention keys.
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
@@ -23,39 +23,29 @@ struct DecAttnP {
     int group;                                    // keys / values of sequence b live at batch index b / group (beams sharing one image's cross-attention K/V)
 };
 
-// One 256-thread workgroup per (sequence, head).  Every global access is a wave-instruction over 8 key (or value) rows x
-// 128 contiguous bytes: lane = (row r = lane >> 3, 16-byte chunk c = lane & 7), wave w of iteration i owns key 32 i + 8 w + r.
-// Phase 1: each lane multiplies its chunk of the key by the matching 8 query dimensions (held in registers), three shuffles
-// sum the 8 chunks of a key, the scores meet in LDS and are soft-maxed by one thread per key.  Phase 2: the same lanes weight
-// their chunk of the value row (requested up front, next to the keys: one memory round trip for both), three shuffles sum
-// the 8 rows of a wave-instruction, the four waves' partial outputs meet in LDS.  NU: 256 NU keys at most.
-template <int NU>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
-    __shared__ float prob[256 * NU];
-    __shared__ float red[8];
-    __shared__ float part[4][64];
-    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// One WAVE per (sequence, head), no LDS and no barrier.  Every global access is a wave-instruction over 8 key (or value) rows x
+// 128 contiguous bytes: lane = (row r = lane >> 3, 16-byte chunk c = lane & 7), iteration i owns key 8 i + r.  Scores: each
+// lane multiplies its chunk of the key by the matching 8 query dimensions (registers), three shuffles sum the 8 chunks, so
+// the 8 lanes of a row all hold that key's score; max and sum run across the wave.  Output: the SAME lanes hold the matching
+// chunk of the value row, weight it by their key's probability, and three shuffles sum the 8 rows of an iteration.
+// The step's own key / value (self-attention) is taken from the projection output directly and stored to the cache on the
+// side.  NI = iterations (8 keys each): 24 -> 192 keys, 40 -> 320 keys.
+template <int NI>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, const int npairs) {
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);          // (sequence, head) of this wave
+    if (pair >= npairs) return;
+    const int b = pair / p.heads, h = pair - b * p.heads, lane = threadIdx.x & 63;
     bf16_t* Kb = p.K + (int64_t)(b / p.group) * p.kb + h * 64;
     bf16_t* Vb = p.V + (int64_t)(b / p.group) * p.kb + h * 64;
     const int tdev = p.tptr ? *p.tptr : 0;
-    const int nkeys = p.tptr ? min(tdev + 1, 256 * NU) : p.nkeys;
-    const int append_at = p.tptr ? min(tdev, 256 * NU - 1) : p.append_at;
-    if (append_at >= 0) {                         // thread d copies dimension d of the new key and value into the cache
-        if (tid < 64) {
-            Kb[(int64_t)append_at * p.kj + tid] = p.knew[(int64_t)b * p.ldnew + h * 64 + tid];
-            Vb[(int64_t)append_at * p.kj + tid] = p.vnew[(int64_t)b * p.ldnew + h * 64 + tid];
-        }
-        __syncthreads();                          // the appended row is read back below by other waves of this workgroup
-    }
+    const int nkeys = p.tptr ? min(tdev + 1, 8 * NI) : p.nkeys;
+    const int append_at = p.tptr ? min(tdev, 8 * NI - 1) : p.append_at;
     const int r = lane >> 3, c = lane & 7;
-    constexpr int NI = 8 * NU;
-    bf16x8 kk[NI], vv[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int j = 32 * i + 8 * w + r;
-        const bool in = j < nkeys;
-        kk[i] = in ? *(const bf16x8*)(Kb + (int64_t)j * p.kj + c * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        vv[i] = in ? *(const bf16x8*)(Vb + (int64_t)j * p.kj + c * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16_t* knew = append_at >= 0 ? p.knew + (int64_t)b * p.ldnew + h * 64 : nullptr;
+    const bf16_t* vnew = append_at >= 0 ? p.vnew + (int64_t)b * p.ldnew + h * 64 : nullptr;
+    if (append_at >= 0) {                         // lane d copies dimension d of the new key and value into the cache
+        Kb[(int64_t)append_at * p.kj + lane] = knew[lane];
+        Vb[(int64_t)append_at * p.kj + lane] = vnew[lane];
     }
     float qc[8];
     {
@@ -63,49 +53,61 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qc[e] = bf2f((bf16_t)q8[e]) * p.scale;
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int j = 32 * i + 8 * w + r;
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a += qc[e] * bf2f((bf16_t)kk[i][e]);
-        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-        if (c == 0) prob[j] = (j < nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j])) ? a : -INFINITY;
-    }
-    __syncthreads();
-    float sc[NU];
+    auto row = [&](const bf16_t* base, const bf16_t* fresh, int j) -> bf16x8 {
+        if (j >= nkeys) return (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        return *(const bf16x8*)((j == append_at ? fresh : base + (int64_t)j * p.kj) + c * 8);
+    };
+    float sc[NI];
     float mx = -INFINITY;
+    constexpr int CH = 8;                          // rows in flight: 8 wave-instructions = 64 keys
 #pragma unroll
-    for (int u = 0; u < NU; ++u) { sc[u] = prob[tid + 256 * u]; mx = fmaxf(mx, sc[u]); }
+    for (int i0 = 0; i0 < NI; i0 += CH) {
+        if (i0 * 8 >= nkeys) {                     // wave-uniform: nothing left
+#pragma unroll
+            for (int u = 0; u < CH; ++u) sc[i0 + u] = -INFINITY;
+            continue;
+        }
+        bf16x8 kk[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) kk[u] = row(Kb, knew, 8 * (i0 + u) + r);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int j = 8 * (i0 + u) + r;
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += qc[e] * bf2f((bf16_t)kk[u][e]);
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+            const bool ok = j < nkeys && (!p.valid || p.valid[(int64_t)b * p.ldvalid + j]);
+            sc[i0 + u] = ok ? a : -INFINITY;
+            mx = fmaxf(mx, sc[i0 + u]);
+        }
+    }
     mx = wave_max(mx);
-    if (lane == 0) red[w] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const bool dead = mx == -INFINITY;            // no usable key (a finished, all-pad row): output zeros
+    const bool dead = mx == -INFINITY;             // no usable key (a finished, all-pad row): output zeros
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) { sc[u] = dead ? 0.f : __expf(sc[u] - mx); sum += sc[u]; prob[tid + 256 * u] = sc[u]; }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + w] = sum;
-    __syncthreads();
-    sum = red[4] + red[5] + red[6] + red[7];
+    for (int i = 0; i < NI; ++i) { sc[i] = dead ? 0.f : __expf(sc[i] - mx); sum += sc[i]; }
+    sum = wave_sum(sum) * 0.125f;                  // every key is counted by the 8 lanes of its row
     const float inv = dead ? 0.f : 1.f / sum;
-    // phase 2: out[d] = inv * sum_j prob[j] * V[j][d]
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const float pj = prob[32 * i + 8 * w + r];           // 0 for keys beyond nkeys (their scores were -inf)
+    for (int i0 = 0; i0 < NI; i0 += CH) {
+        if (i0 * 8 >= nkeys) continue;
+        bf16x8 vv[CH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += pj * bf2f((bf16_t)vv[i][e]);
+        for (int u = 0; u < CH; ++u) vv[u] = row(Vb, vnew, 8 * (i0 + u) + r);
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += sc[i0 + u] * bf2f((bf16_t)vv[u][e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 8, 64); o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
     if (r == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part[w][c * 8 + e] = o[e];
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 pk = (u32x4){pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv), pack_bf2(o[4] * inv, o[5] * inv), pack_bf2(o[6] * inv, o[7] * inv)};
+        *(u32x4*)(p.out + (int64_t)b * p.ldo + h * 64 + c * 8) = pk;
     }
-    __syncthreads();
-    if (tid < 64) p.out[(int64_t)b * p.ldo + h * 64 + tid] = f2bf((part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * inv);
 }
 
 // beam re-ordering: dst[l][b][j][:] = src[l][idx[b]][j][:] for j < len (16-byte chunks)
@@ -133,12 +135,14 @@ int kzv_step_inc(int* d_t, hipStream_t s) {
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
                     int append_at, hipStream_t s, const int* tptr, int group) {
-    if (nkeys < 1 || nkeys > 512) return kzv_fail(KZV_E_ARG, "attn_decode: 1..512 keys");
+    if (nkeys < 1 || nkeys > 320) return kzv_fail(KZV_E_ARG, "attn_decode: 1..320 keys");
+    if (ldq % 8 || ldo % 8 || (knew && ldnew % 8)) return kzv_fail(KZV_E_ARG, "attn_decode: rows must be 16-byte aligned");
     if (group < 1 || (append_at >= 0 && group != 1)) return kzv_fail(KZV_E_ARG, "attn_decode: shared keys cannot be appended to");
     if (kj % 8) return kzv_fail(KZV_E_ARG, "attn_decode: key rows must be 16-byte aligned");
     DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr, group};
-    if (nkeys <= 256) hipLaunchKernelGGL(attn_decode_kernel<1>, dim3(B * heads), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attn_decode_kernel<2>, dim3(B * heads), dim3(256), 0, s, p);
+    const int npairs = B * heads;
+    if (nkeys <= 192) hipLaunchKernelGGL(attn_decode_kernel<24>, dim3((npairs + 3) / 4), dim3(256), 0, s, p, npairs);
+    else hipLaunchKernelGGL(attn_decode_kernel<40>, dim3((npairs + 3) / 4), dim3(256), 0, s, p, npairs);
     return kzv_check_launch("attn_decode");
 }
 
