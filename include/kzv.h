@@ -206,8 +206,10 @@ int kzv_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
 int kzv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma,
                       float* dx, int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, void* stream);
 
-/* Multi-head attention, head_dim 64, one workgroup per (batch, head).
- * mode 0: no mask (ViT self-attn / decoder cross-attn); mode 1: causal AND key-not-pad (decoder self). */
+/* Multi-head attention, one workgroup per (batch, head) on the MFMA kernels for head_dim 64 (the benchmark geometry and the
+ * decoder); other head dimensions (multiples of 8 up to 128; the reference's CLI default ViT is 768 / 8 heads = 96,
+ * scripts/train_trocr.py:41-43) take a plain fp32 kernel -- same results, several times slower (attention_generic.hip).
+ * mode 0: no mask (ViT self-attn / decoder cross-attn); mode 1: causal AND key-not-pad (decoder self; head_dim 64 only). */
 typedef struct kzv_attn_args {
     const void* Q; const void* K; const void* V;   /* bf16, row strides ldq/ldk/ldv, head h at col h*64 */
     void* O;                                        /* bf16 [B*Sq, ldo] */
@@ -217,6 +219,7 @@ typedef struct kzv_attn_args {
     const int64_t* ids; int64_t ld_ids; int32_t pad_id;   /* mode 1: decoder input ids [B, ld_ids] */
     int32_t B, heads, Sq, Sk, mode;
     float drop_p; uint32_t drop_key;
+    int32_t head_dim;                                     /* 0 = 64; head h sits at column h * head_dim */
 } kzv_attn_args;
 int kzv_attn_fwd(const kzv_attn_args* a, void* stream);
 int kzv_attn_bwd(const kzv_attn_args* a, void* stream);

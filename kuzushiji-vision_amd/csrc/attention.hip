@@ -446,7 +446,15 @@ extern "C" int kzv_debug_bwd_stamps(unsigned long long* host64) {
 }
 #endif
 
+int kzv_attn_generic(const kzv_attn_args* a, int D, bool bwd, hipStream_t s);      // attention_generic.hip
+
 extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
+    if (a && a->head_dim != 0 && a->head_dim != 64) {
+        if (!a->Q || !a->K || !a->V || !a->O) return kzv_fail(KZV_E_ARG, "attn: null operand");
+        if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8) return kzv_fail(KZV_E_ARG, "attn: row strides must be multiples of 8");
+        KzvProfScope prof(2, 4.0 * a->B * a->heads * (double)a->Sq * a->Sk * a->head_dim, (hipStream_t)stream);
+        return kzv_attn_generic(a, a->head_dim, false, (hipStream_t)stream);
+    }
     AttnP p;
     if (int rc = fill(p, a, false)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -463,6 +471,12 @@ extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
 }
 
 extern "C" int kzv_attn_bwd(const kzv_attn_args* a, void* stream) {
+    if (a && a->head_dim != 0 && a->head_dim != 64) {
+        if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->dQ || !a->dK || !a->dV || !a->LSE) return kzv_fail(KZV_E_ARG, "attn_bwd: null operand");
+        if ((a->ldq | a->ldk | a->ldv | a->ldo) % 8) return kzv_fail(KZV_E_ARG, "attn: row strides must be multiples of 8");
+        KzvProfScope prof(3, 10.0 * a->B * a->heads * (double)a->Sq * a->Sk * a->head_dim, (hipStream_t)stream);
+        return kzv_attn_generic(a, a->head_dim, true, (hipStream_t)stream);
+    }
     AttnP p;
     if (int rc = fill(p, a, true)) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -328,13 +328,13 @@ int join_side(kzv_model* m, hipStream_t s) {
 
 int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, const bf16_t* K, const bf16_t* V, int64_t ldkv,
          bf16_t* O, int64_t ldo, float* LSE, const bf16_t* dO, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int heads, int Sq, int Sk,
-         float drop_p, uint32_t drop_key, hipStream_t s, int batch = 0) {
+         float drop_p, uint32_t drop_key, hipStream_t s, int batch = 0, int head_dim = 64) {
     kzv_attn_args a;
     memset(&a, 0, sizeof(a));
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE; a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = ldo;
     a.ids = m->labels; a.ld_ids = m->L; a.pad_id = m->c.pad_id;
-    a.B = batch > 0 ? batch : m->B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.mode = mode; a.drop_p = drop_p; a.drop_key = drop_key;
+    a.B = batch > 0 ? batch : m->B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.head_dim = head_dim; a.mode = mode; a.drop_p = drop_p; a.drop_key = drop_key;
     return bwd ? kzv_attn_bwd(&a, s) : kzv_attn_fwd(&a, s);
 }
 
@@ -367,7 +367,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         KZV_TRY(kzv_ln_fwd_ex(a.x_in, P + e.ln1w, P + e.ln1b, a.ln1, nullptr, a.st1, Me, He, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.ln1, He, m->w_eqkv[i], false, Me, 3 * He, He, 3 * He, P + e.qkvb, a.qkv, 3 * He, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, false, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, nullptr, nullptr, nullptr, nullptr,
-                     c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, B));
+                     c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, B, He / c.enc_heads));
         KZV_TRY(gemm(a.ctx, He, m->w_eo[i], false, Me, He, He, He, P + e.ob, a.x_mid, He, KZV_EPI_RESID, s, a.x_in, nullptr, 0,
                      dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
         KZV_TRY(kzv_ln_fwd_ex(a.x_mid, P + e.ln2w, P + e.ln2b, a.ln2, nullptr, a.st2, Me, He, eps, 1, 0, 0.f, 0, s));
@@ -539,7 +539,7 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
         KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e2, He, a.ctx, He, G + e.ow, Me, He, He, He, G + e.ob));
         KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
         KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
-                     m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+                     m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, 0, He / c.enc_heads));
         KZV_TRY(join_side(m, s));
         KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
         KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
@@ -562,7 +562,7 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     KZV_TRY(gemm(m->dy_e, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
     KZV_TRY(wait_cls(m, CLS_DQKV, s));    // dqkv_e is rewritten below
     KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
-                 m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s));
+                 m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, 0, He / c.enc_heads));
     KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
     KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
     // ... and the masked copy for the fc2 site of the layer below (layer 0 hands fp32 dx_e to the embedding backward)
@@ -590,8 +590,10 @@ extern "C" int kzv_model_create(const kzv_config* cfg, kzv_model** out) {
     const kzv_config& c = *cfg;
     if (c.patch_h <= 0 || c.patch_w <= 0 || c.image_h % c.patch_h || c.image_w % c.patch_w)
         return kzv_fail(KZV_E_ARG, "model_create: image %dx%d not divisible by patch %dx%d", c.image_h, c.image_w, c.patch_h, c.patch_w);
-    if (c.enc_heads <= 0 || c.dec_heads <= 0 || c.enc_hidden != 64 * c.enc_heads || c.dec_hidden != 64 * c.dec_heads)
-        return kzv_fail(KZV_E_ARG, "model_create: head_dim must be 64 (hidden = 64 * heads)");
+    if (c.enc_heads <= 0 || c.dec_heads <= 0 || c.dec_hidden != 64 * c.dec_heads)
+        return kzv_fail(KZV_E_ARG, "model_create: the decoder's head_dim must be 64 (hidden = 64 * heads)");
+    if (c.enc_hidden % c.enc_heads || (c.enc_hidden / c.enc_heads) % 8 || c.enc_hidden / c.enc_heads > 128)
+        return kzv_fail(KZV_E_ARG, "model_create: the encoder's head_dim must be a multiple of 8 up to 128 (64 takes the MFMA attention kernels)");
     if (c.enc_ffn % 64 || c.dec_ffn % 64 || (c.channels * c.patch_h * c.patch_w) % 64 || c.patch_w % 8)
         return kzv_fail(KZV_E_ARG, "model_create: ffn sizes and C*ph*pw must be multiples of 64, patch_w of 8");
     const int np = (c.image_h / c.patch_h) * (c.image_w / c.patch_w);

@@ -49,7 +49,7 @@ class kzv_attn_args(C.Structure):
                 ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
                 ("ids", C.c_void_p), ("ld_ids", C.c_int64), ("pad_id", C.c_int32),
                 ("B", C.c_int32), ("heads", C.c_int32), ("Sq", C.c_int32), ("Sk", C.c_int32), ("mode", C.c_int32),
-                ("drop_p", C.c_float), ("drop_key", C.c_uint32)]
+                ("drop_p", C.c_float), ("drop_key", C.c_uint32), ("head_dim", C.c_int32)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)

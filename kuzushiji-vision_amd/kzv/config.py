@@ -70,8 +70,11 @@ class ModelConfig:
     def validate(self) -> None:
         if self.enc_hidden % self.enc_heads or self.dec_hidden % self.dec_heads:
             raise ValueError("hidden size must be a multiple of the number of heads")
-        if self.enc_hidden // self.enc_heads != 64 or self.dec_hidden // self.dec_heads != 64:
-            raise ValueError("the HIP attention kernels are built for head_dim == 64")
+        if self.dec_hidden // self.dec_heads != 64:
+            raise ValueError("the decoder's attention / generation kernels are built for head_dim == 64")
+        eh = self.enc_hidden // self.enc_heads
+        if eh % 8 or eh > 128:      # 64: MFMA kernels; others (the reference CLI's default 768 / 8 = 96): the plain fp32 kernel
+            raise ValueError("the encoder's head_dim must be a multiple of 8 up to 128")
         for k in (self.enc_hidden, self.enc_ffn, self.dec_hidden, self.dec_ffn, self.patch_dim):
             if k % 64:
                 raise ValueError(f"GEMM reduction dims must be multiples of 64 (got {k})")

@@ -29,9 +29,9 @@ def parse_args(argv=None):
     p.add_argument("--patch_size", type=int, nargs=2, default=[16, 16])
     p.add_argument("--encoder_hidden_size", type=int, default=768)
     p.add_argument("--encoder_num_layers", type=int, default=12)
-    p.add_argument("--encoder_num_heads", type=int, default=12,
-                   help="the reference defaults to 8 (head_dim 96, scripts/train_trocr.py:43); this engine's attention kernels are built "
-                        "for head_dim 64, so the default here is hidden_size / 64 = 12 (ViT-B/16)")
+    p.add_argument("--encoder_num_heads", type=int, default=8,
+                   help="reference default 8 = head_dim 96 (scripts/train_trocr.py:43), which runs on the plain fp32 attention kernel; "
+                        "hidden_size / 64 heads (12 for ViT-B/16) take the MFMA attention kernels, several times faster")
     p.add_argument("--max_length", type=int, default=128)
     # training (:47-54)
     p.add_argument("--batch_size", type=int, default=64)
@@ -76,10 +76,9 @@ def main(argv=None):
         raise SystemExit("this engine runs on MI355X GPUs only (the reference CPU Trainer branch is not provided)")
     if args.precision != "bf16-mixed":
         raise SystemExit("the engine implements bf16-mixed (scripts/train_trocr.py:68 default) only")
-    if args.encoder_hidden_size != 64 * args.encoder_num_heads:
-        raise SystemExit(f"head_dim {args.encoder_hidden_size / max(1, args.encoder_num_heads):g} is not supported: the attention kernels are built "
-                         "for head_dim 64, so --encoder_hidden_size must equal 64 * --encoder_num_heads (the reference's own default, 768 / 8 heads = "
-                         "head_dim 96, is NOT available; use --encoder_num_heads 12)")
+    hd = args.encoder_hidden_size / max(1, args.encoder_num_heads)
+    if hd != int(hd) or int(hd) % 8 or hd > 128:
+        raise SystemExit(f"encoder head_dim {hd:g} is not supported: --encoder_hidden_size / --encoder_num_heads must be a multiple of 8 up to 128")
     rank, world, local = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU with torch.distributed.run")

@@ -75,6 +75,13 @@ def test_bad_geometry_is_rejected(lib):
     assert lib.kzv_model_create(C.byref(c), C.byref(h)) == -1
     assert b"not divisible" in lib.kzv_last_error()
     c.image_h = 32
-    c.enc_heads = 4   # head_dim 32
+    c.enc_heads = 32  # encoder head_dim 4: not a multiple of 8
     assert lib.kzv_model_create(C.byref(c), C.byref(h)) == -1
-    assert b"head_dim" in lib.kzv_last_error()
+    assert b"encoder's head_dim" in lib.kzv_last_error()
+    c.enc_heads = 4   # encoder head_dim 32: allowed (plain fp32 attention kernel); the decoder's must stay 64
+    c.dec_heads = 2
+    assert lib.kzv_model_create(C.byref(c), C.byref(h)) == -1
+    assert b"decoder's head_dim" in lib.kzv_last_error()
+    c.dec_heads = 1
+    assert lib.kzv_model_create(C.byref(c), C.byref(h)) == 0
+    lib.kzv_model_destroy(h)

@@ -68,12 +68,12 @@ def test_config0_cli_32_synthetic_crops(tmp_path):
 
 
 def test_cli_with_the_default_model_flags_trains_validates_and_tests(tmp_path):
-    """`python -m kzv.train` with every MODEL flag at its default (1024x64 columns = 257 tokens, ViT-B/16 768/12 layers,
-    max_length 128; ADVICE r01: the defaults must build and run): two steps, the half-epoch validation with beam-4 decoding
+    """`python -m kzv.train` with every MODEL flag at its default (1024x64 columns = 257 tokens, hidden 768 / 12 layers /
+    8 heads = head_dim 96 on the plain fp32 attention kernel, max_length 128; ADVICE r01: the defaults must build and run): two steps, the half-epoch validation with beam-4 decoding
     over 256 cross-attention keys, the checkpoint, and the post-fit test phase on the best checkpoint."""
     from kzv.train import main, parse_args
     a = parse_args([])
-    assert a.encoder_hidden_size == 64 * a.encoder_num_heads
+    assert (a.encoder_hidden_size, a.encoder_num_heads, a.image_size) == (768, 8, [1024, 64])      # head_dim 96, 257 tokens
     hist = main(["--synthetic", "8", "--batch_size", "4", "--max_epochs", "1", "--output_dir", str(tmp_path), "--experiment_name", "d"])
     assert hist and all(np.isfinite(v) for _, v in hist)
     assert main.test_metrics is not None and np.isfinite(main.test_metrics["test_loss"]) and 0.0 <= main.test_metrics["test_cer"]
@@ -210,3 +210,29 @@ def test_generate_at_the_reference_default_geometry_1024x64(tmp_path):
         assert float((g0[:, :w] == g1[:, :w]).float().mean()) > 0.9       # untrained, nearly flat logits: rare ties may flip
     out = m(pxt)                     # the inference branch as validation_step calls it (beam 4, max_length 128)
     assert out["generated_ids"].shape[0] == 3
+
+
+def test_reference_default_head_dim_96_matches_oracle(tmp_path):
+    """hidden 192 / 2 heads = head_dim 96 on the 1024x64 default columns (257 tokens): the geometry family of the reference's
+    CLI defaults (768 / 8 heads), forward, loss and every gradient vs the oracle, dropout off and (mask replay) on."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _replay import step_masks
+    base = dataclasses.replace(tiny_config(), image_h=1024, image_w=64, enc_hidden=192, enc_heads=2, enc_ffn=256)
+    for cfg, seed in ((_no_dropout(base), None), (base, 4321)):
+        m = _make(cfg, tmp_path / str(seed), 11)
+        px, lab = synthetic_batch(cfg, 2, 16, seed=4, min_chars=3, max_chars=15)
+        m.train()
+        loss, logits = m.forward_loss(torch.from_numpy(px), torch.from_numpy(lab), want_logits=True, seed=seed or 1)
+        m.backward()
+        torch.cuda.synchronize()
+        masks = step_masks(cfg, seed, 2, 15) if seed else None
+        r = O.forward_backward(cfg, P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 11)), px, lab, masks=masks)
+        assert np.abs(logits.cpu().numpy() - r["logits"]).max() < 3e-2
+        assert abs(float(loss.item()) - r["loss"]) < 5e-3
+        g = m.grad_dict()
+        for k, v in r["grads"].items():
+            if v is None or k.endswith("key.bias"):
+                continue
+            got = g[k].cpu().numpy().reshape(v.shape)
+            assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, (seed, k)

@@ -195,7 +195,7 @@ def test_train_cli_flag_surface():
     a = parse_args([])
     # defaults of scripts/train_trocr.py:23-71
     assert (a.image_size, a.patch_size, a.encoder_hidden_size, a.encoder_num_layers) == ([1024, 64], [16, 16], 768, 12)
-    assert a.encoder_num_heads == 12      # NOT the reference's 8 (head_dim 96): the attention kernels are built for head_dim 64 (kzv/train.py help)
+    assert a.encoder_num_heads == 8       # the reference's default: head_dim 96, served by the plain fp32 attention kernel
     assert (a.batch_size, a.learning_rate, a.weight_decay, a.beta1, a.beta2, a.epsilon, a.max_epochs) == (64, 1e-4, 0, 0.9, 0.999, 1e-8, 50)
     assert (a.gpus, a.precision, a.max_length, a.num_workers) == (1, "bf16-mixed", 128, 8)
     b = parse_args(["--train_data_dir", "x", "--val_data_dir", "y", "--accelerator", "gpu", "--devices", "2", "--seed", "7"])

@@ -294,3 +294,37 @@ def test_attention_dropout_consistent_between_fwd_and_bwd(lib):
     assert (outs[1] - outs[0]).mean().abs().item() < 2e-3
     rel = (outs[1] - outs[0]).std().item() / outs[0].std().item()
     assert 0.1 < rel < 1.0
+
+
+@pytest.mark.parametrize("B,heads,S,D,drop", [(2, 3, 37, 96, 0.0), (2, 2, 257, 96, 0.1), (1, 4, 70, 32, 0.1), (1, 1, 161, 128, 0.0)])
+def test_attention_other_head_dims_fwd_bwd(lib, B, heads, S, D, drop):
+    """head_dim != 64 (the reference CLI's default ViT: 768 / 8 heads = 96) runs on the plain fp32 kernel of
+    attention_generic.hip: forward and backward against fp32 torch math, with the dropout mask the library reports."""
+    torch.manual_seed(S + D)
+    H = heads * D
+    qkv = (torch.randn(B * S, 3 * H, device=DEV) * 0.5).bfloat16()
+    dO = (torch.randn(B * S, H, device=DEV) * 0.5).bfloat16()
+    O = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, S, device=DEV)
+    dqkv = torch.zeros_like(qkv)
+    key = 1234
+    a = L.kzv_attn_args(Q=qkv.data_ptr(), K=qkv[:, H:].data_ptr(), V=qkv[:, 2 * H:].data_ptr(), O=O.data_ptr(), LSE=lse.data_ptr(),
+                        dO=dO.data_ptr(), dQ=dqkv.data_ptr(), dK=dqkv[:, H:].data_ptr(), dV=dqkv[:, 2 * H:].data_ptr(),
+                        ldq=3 * H, ldk=3 * H, ldv=3 * H, ldo=H, ids=None, ld_ids=0, pad_id=1, B=B, heads=heads, Sq=S, Sk=S, mode=0,
+                        drop_p=drop, drop_key=key, head_dim=D)
+    L.check(lib.kzv_attn_fwd(C.byref(a), _st()), "attn_fwd")
+    L.check(lib.kzv_attn_bwd(C.byref(a), _st()), "attn_bwd")
+    mask = torch.ones(B * heads * S, S, device=DEV)
+    if drop:
+        L.check(lib.kzv_debug_dropout_mask(key, drop, B * heads * S, S, (S + 1) & ~1, mask.data_ptr(), _st()), "mask")
+    x = qkv.float().view(B, S, 3, heads, D).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)      # [3, B, h, S, D]
+    sc = (x[0] @ x[1].transpose(-1, -2)) * D ** -0.5
+    pm = torch.softmax(sc, -1) * mask.view(B, heads, S, S)
+    out = pm @ x[2]
+    out.backward(dO.float().view(B, S, heads, D).permute(0, 2, 1, 3))
+    want_o = out.detach().permute(0, 2, 1, 3).reshape(B * S, H)
+    assert (O.float() - want_o).abs().max().item() < 2e-2 * want_o.abs().max().item() + 2e-3
+    assert (lse - torch.logsumexp(sc.detach(), -1)).abs().max().item() < 1e-3
+    want_g = x.grad.permute(1, 3, 0, 2, 4).reshape(B * S, 3 * H)
+    err = (dqkv.float() - want_g).abs().max().item()
+    assert err < 3e-2 * want_g.abs().max().item() + 2e-3, err
