@@ -163,7 +163,7 @@ def test_two_rank_stepper_on_one_gpu(tmp_path):
         step_k = float(np.abs(mine[k] - init[k].reshape(mine[k].shape)).max())       # how far the optimizer moved this tensor
         # the two runs differ by float-atomic summation order in the gradients; Adam's normalisation turns that into a
         # small fraction of the update (elements whose gradient sits near the rounding floor): compare against the update
-        assert np.abs(mine[k] - theirs[k]).max() < 0.02 * step_k + 1e-7, (k, step_k)
+        assert np.abs(mine[k] - theirs[k]).max() < 0.05 * step_k + 1e-7, (k, step_k)
         moved = max(moved, step_k)
     assert moved > 1e-3                   # the steps after the optimizer's silent phase moved the parameters
 
@@ -236,3 +236,48 @@ def test_reference_default_head_dim_96_matches_oracle(tmp_path):
                 continue
             got = g[k].cpu().numpy().reshape(v.shape)
             assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, (seed, k)
+
+
+def test_generation_step_at_decoder_width_256(tmp_path):
+    """The reference decoder width (256 / 4 heads, K up to 768): the generation step's few-rows GEMMs (gemm_rows_kernel, all K
+    splits) and the 4-head decode attention.  Cached step (eager and graph-replayed) against the prefix
+    recompute (training kernels) at every step, on a 1-layer ViT-B-wide encoder + 2-layer decoder."""
+    import ctypes as C
+    from kzv import _lib as L
+    cfg = dataclasses.replace(_no_dropout(vit_b_config(dec_layers=2)), enc_layers=1)
+    m = _make(cfg, tmp_path, 9)
+    m.eval()
+    B, Lh = 5, 12
+    px, lab = synthetic_batch(cfg, B, Lh, seed=4, min_chars=4, max_chars=11)
+    ids = torch.from_numpy(lab).cuda()
+    ids[:, 0] = cfg.bos_id
+    pxt = torch.from_numpy(px).cuda()
+    lib = L.load()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        m.forward_loss(pxt, ids, want_logits=False, seed=0)
+        a = torch.empty(B, cfg.vocab, device="cuda"); b = torch.empty(B, cfg.vocab, device="cuda"); g = torch.empty(B, cfg.vocab, device="cuda")
+        valid = torch.zeros(B, Lh, dtype=torch.uint8, device="cuda")
+        posids = torch.empty(B, dtype=torch.int32, device="cuda")
+        tok = torch.empty(B, dtype=torch.int64, device="cuda")
+        for use_graph in (False, True):
+            valid.zero_()
+            if use_graph:
+                L.check(lib.kzv_decode_begin(m._h, L.stream_handle()), "begin")
+            for t in range(Lh - 1):
+                tok.copy_(ids[:, t])
+                live = tok != cfg.pad_id
+                valid[:, t] = live.to(torch.uint8)
+                posids.copy_(torch.where(live, torch.full_like(tok, t + 1 + cfg.pad_id), torch.full_like(tok, cfg.pad_id)).to(torch.int32))
+                if use_graph:
+                    L.check(lib.kzv_decode_step_graph(m._h, tok.data_ptr(), posids.data_ptr(), valid.data_ptr(), Lh, g.data_ptr(), L.stream_handle()), "graph step")
+                    out = g
+                else:
+                    L.check(lib.kzv_decode_step(m._h, tok.data_ptr(), posids.data_ptr(), t, valid.data_ptr(), Lh, a.data_ptr(), L.stream_handle()), "step")
+                    out = a
+                L.check(lib.kzv_set_active_length(m._h, t + 1), "len")
+                L.check(lib.kzv_decode_logits(m._h, ids.data_ptr(), t, b.data_ptr(), L.stream_handle()), "logits")
+                torch.cuda.synchronize()
+                rows = live.cpu().numpy()
+                assert not rows.any() or np.abs((out - b).cpu().numpy()[rows]).max() < 2e-2, (use_graph, t)
+    torch.cuda.synchronize()
