@@ -281,3 +281,21 @@ def test_generation_step_at_decoder_width_256(tmp_path):
                 rows = live.cpu().numpy()
                 assert not rows.any() or np.abs((out - b).cpu().numpy()[rows]).max() < 2e-2, (use_graph, t)
     torch.cuda.synchronize()
+
+
+def test_bench_multi_rank_path_rehearsal(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the one
+    GPU of a dev box: both ranks on device 0, collectives over gloo (KZV_FORCE_DEVICE / KZV_DIST_BACKEND).  Checks the N > 1
+    code path of the benchmark itself -- rendezvous, per-rank batches, segmented backward + bucketed all-reduce, barrier +
+    max-over-ranks timing, the one JSON line with the whole-job value."""
+    import json
+    env = dict(os.environ, KZV_DIST_BACKEND="gloo", KZV_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["steps"] == 2 and np.isfinite(d["config"]["final_loss"]) and d["cpu_baseline"] is None
