@@ -299,3 +299,22 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and d["steps"] == 2 and np.isfinite(d["config"]["final_loss"]) and d["cpu_baseline"] is None
+
+
+def test_labels_longer_than_the_position_table_are_refused(tmp_path):
+    """RoBERTa position ids run to (non-pad decoder inputs) + pad_id and index a [max_pos, H] table (HF
+    modeling_roberta.py:142-155): the reference raises IndexError for longer labels.  The host mirror raises the same for
+    labels it can see on the CPU; for device-resident labels the kernels clamp and raise a flag that kzv_check_positions reads."""
+    from kzv import _lib as L
+    cfg = _no_dropout(tiny_config())                  # max_pos 40, pad_id 1: at most 38 non-pad decoder inputs
+    m = _make(cfg, tmp_path, 1)
+    px, _ = synthetic_batch(cfg, 2, 41, seed=1)
+    lab = np.full((2, 41), 7, dtype=np.int64)         # 40 non-pad decoder inputs
+    with pytest.raises(IndexError, match="index out of range"):
+        m(torch.from_numpy(px), torch.from_numpy(lab))
+    m.forward_loss(torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda())          # device-resident: not inspected on the host
+    assert L.load().kzv_check_positions(m._h, L.stream_handle()) == -1
+    assert b"labels too long" in L.load().kzv_last_error()
+    lab[:, 30:] = cfg.pad_id
+    m.forward_loss(torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda())
+    assert L.load().kzv_check_positions(m._h, L.stream_handle()) == 0                 # the flag is cleared by every forward
