@@ -167,8 +167,11 @@ int kzv_clip_and_step_ema(float* d_params, float* d_z, float* d_v, const float* 
 int kzv_lerp_params(float* d_params, const float* d_z, int64_t n, float w, void* stream);
 
 /* -------------------------------------------------------- per-op entry points (unit parity tests) */
-enum { KZV_EPI_BF16 = 0, KZV_EPI_F32 = 1, KZV_EPI_GELU = 2, KZV_EPI_RESID = 3, KZV_EPI_DGELU = 4,
-       KZV_EPI_GELU_F32 = 5 /* like GELU but C is fp32 (feeds a LayerNorm) */ };
+enum { KZV_EPI_BF16 = 0, KZV_EPI_F32 = 1,
+       KZV_EPI_GELU = 2,       /* C = gelu_erf(acc + bias) bf16, aux = gelu_erf'(acc + bias) bf16 (saved for backward) */
+       KZV_EPI_RESID = 3,      /* C = dropout(acc + bias) + resid, fp32 */
+       KZV_EPI_DGELU = 4,      /* C = acc * aux, bf16 (aux = the derivative saved by the forward GELU epilogue) */
+       KZV_EPI_GELU_F32 = 5    /* like GELU but C is fp32 (feeds a LayerNorm) */ };
 
 /* C[M,N] = A[M,K] . B[N,K]^T (+bias) with a fused epilogue; bf16 operands, fp32 accumulate (MFMA).
  * Replaces every nn.Linear forward / input-gradient on the path. */
@@ -178,7 +181,7 @@ typedef struct kzv_gemm_nt_args {
     void* C; int64_t ldc;             /* bf16 or fp32 [M,N] by epilogue */
     const float* bias;                /* fp32 [n_valid] or NULL */
     const float* resid; int64_t ldr;  /* KZV_EPI_RESID: fp32 [M,N] */
-    void* aux; int64_t ldaux;         /* GELU: bf16 pre-activation OUT; DGELU: bf16 pre-activation IN */
+    void* aux; int64_t ldaux;         /* GELU: bf16 gelu'(pre-activation) OUT (what backward needs); DGELU: the same IN */
     int32_t M, N, K, n_valid;         /* N = columns stored (mult of 4), rows of B >= n_valid read as 0 */
     float drop_p; uint32_t drop_key;  /* KZV_EPI_RESID dropout on (acc+bias); p=0 -> off */
 } kzv_gemm_nt_args;

@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ gi
                     d.x *= drop_keep(b0, 0, thr16, inv_keep); d.y *= drop_keep(b0, 1, thr16, inv_keep);
                     d.z *= drop_keep(b1, 0, thr16, inv_keep); d.w *= drop_keep(b1, 1, thr16, inv_keep);
                 }
-                if (gelu_pre) {   // backward of GELU: multiply by gelu'(saved pre-activation)
+                if (gelu_pre) {   // backward of GELU: multiply by the derivative the forward epilogue saved
                     const uint2 u = *(const uint2*)(gelu_pre + (int64_t)r * N + col);
-                    d.x *= gelu_erf_grad(bf2f(u.x & 0xffff)); d.y *= gelu_erf_grad(bf2f(u.x >> 16));
-                    d.z *= gelu_erf_grad(bf2f(u.y & 0xffff)); d.w *= gelu_erf_grad(bf2f(u.y >> 16));
+                    d.x *= bf2f(u.x & 0xffff); d.y *= bf2f(u.x >> 16);
+                    d.z *= bf2f(u.y & 0xffff); d.w *= bf2f(u.y >> 16);
                 }
                 const uint2 pk = make_uint2(pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
                 *(uint2*)(out + (int64_t)r * N + col) = pk;

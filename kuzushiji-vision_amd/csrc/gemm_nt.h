@@ -14,7 +14,7 @@ struct NtParams {
 };
 
 // One thread finishes 4 consecutive columns n0..n0+3 of output row m: v = accumulator + bias on entry;
-// r4 = the residual (RESID), u2 = the saved pre-activation as 4 bf16 (DGELU), both loaded by the caller.
+// r4 = the residual (RESID), u2 = the saved GELU derivative as 4 bf16 (DGELU), both loaded by the caller.
 // Outputs are written once and next read by a later kernel: stream them past L2 (global_store ... nt) so the
 // operand panels stay cached and no dirty backlog waits for the end-of-kernel write-back (-3..4 % on the ViT GEMMs).
 #ifndef KZV_NT_PLAIN_STORES
@@ -33,12 +33,15 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
         nt_st((uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0), make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])));
     } else if (EPI == KZV_EPI_F32) {
         nt_st((float4*)((float*)p.C + (int64_t)m * p.ldc + n0), make_float4(v[0], v[1], v[2], v[3]));
-    } else if (EPI == KZV_EPI_GELU) {
-        nt_st((uint2*)(p.aux + (int64_t)m * p.ldaux + n0), make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])));
-        nt_st((uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0), make_uint2(pack_bf2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]))));
-    } else if (EPI == KZV_EPI_GELU_F32) {
-        nt_st((uint2*)(p.aux + (int64_t)m * p.ldaux + n0), make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])));
-        nt_st((float4*)((float*)p.C + (int64_t)m * p.ldc + n0), make_float4(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])));
+    } else if (EPI == KZV_EPI_GELU || EPI == KZV_EPI_GELU_F32) {
+        // aux = gelu'(pre-activation): the erf / exp the activation needs give the derivative for three more FMAs, and the
+        // backward epilogue (DGELU) becomes a plain multiply instead of a second erf + exp per element
+        float y[4], d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gelu_erf_both(v[r], &y[r], &d[r]);
+        nt_st((uint2*)(p.aux + (int64_t)m * p.ldaux + n0), make_uint2(pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])));
+        if (EPI == KZV_EPI_GELU) nt_st((uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0), make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])));
+        else nt_st((float4*)((float*)p.C + (int64_t)m * p.ldc + n0), make_float4(y[0], y[1], y[2], y[3]));
     } else if (EPI == KZV_EPI_RESID) {
         if (p.drop_thr16) {
             const unsigned e = (unsigned)m * (unsigned)p.N + (unsigned)n0;
@@ -50,10 +53,10 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
         }
         nt_st((float4*)((float*)p.C + (int64_t)m * p.ldc + n0), make_float4(v[0] + r4.x, v[1] + r4.y, v[2] + r4.z, v[3] + r4.w));
     } else if (EPI == KZV_EPI_DGELU) {
-        v[0] *= gelu_erf_grad(bf2f((bf16_t)(u2.x & 0xffff)));
-        v[1] *= gelu_erf_grad(bf2f((bf16_t)(u2.x >> 16)));
-        v[2] *= gelu_erf_grad(bf2f((bf16_t)(u2.y & 0xffff)));
-        v[3] *= gelu_erf_grad(bf2f((bf16_t)(u2.y >> 16)));
+        v[0] *= bf2f((bf16_t)(u2.x & 0xffff));          // u2 = gelu'(pre-activation), stored by the forward GELU epilogue
+        v[1] *= bf2f((bf16_t)(u2.x >> 16));
+        v[2] *= bf2f((bf16_t)(u2.y & 0xffff));
+        v[3] *= bf2f((bf16_t)(u2.y >> 16));
         nt_st((uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0), make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])));
     }
 }

@@ -71,6 +71,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
     kzv_erf_parts(x, &er, &e);
     return 0.5f * x * (1.f + er);
 }
+// GELU and its derivative from ONE erf / exp evaluation (the forward epilogues store the derivative for backward)
+__device__ __forceinline__ void gelu_erf_both(float x, float* y, float* dy) {
+    float er, e;
+    kzv_erf_parts(x, &er, &e);
+    const float cdf = 0.5f * (1.f + er);
+    *y = x * cdf;
+    *dy = fmaf(x * 0.39894228040143268f, e, cdf);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     float er, e;
     kzv_erf_parts(x, &er, &e);

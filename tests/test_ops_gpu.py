@@ -56,17 +56,18 @@ def test_gemm_nt_epilogues(lib, small_gemm_kernel, M, N, K):
     aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     got = _gemm_nt(lib, A, B, L.EPI_GELU, bias, aux=aux).float()
     assert (got - torch.nn.functional.gelu(ref)).abs().max().item() < 2 ** -8 * scale
-    assert (aux.float() - ref).abs().max().item() < 2 ** -8 * scale
+    xr = ref.double()
+    dref = (0.5 * (1 + torch.erf(xr / 2 ** 0.5)) + xr * torch.exp(-0.5 * xr * xr) / (2 * torch.pi) ** 0.5).float()
+    assert (aux.float() - dref).abs().max().item() < 2 ** -8 * 1.2                 # aux = gelu'(pre-activation), |gelu'| <= 1.13
     got = _gemm_nt(lib, A, B, 5, bias, aux=aux)
     assert (got - torch.nn.functional.gelu(ref)).abs().max().item() < 2e-5 * scale + 1e-5
     res = torch.randn(M, N, device=DEV)
     got = _gemm_nt(lib, A, B, L.EPI_RESID, bias, resid=res)
     assert (got - ref - res).abs().max().item() < 2e-5 * scale + 1e-5
-    # DGELU: C = (A.B^T) * gelu'(aux)
-    pre = torch.randn(M, N, device=DEV).bfloat16()
-    got = _gemm_nt(lib, A, B, L.EPI_DGELU, None, aux=pre).float()
-    x = pre.float().double()
-    gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    # DGELU: C = (A.B^T) * aux, aux = the derivative saved by the forward epilogue
+    gp16 = (torch.rand(M, N, device=DEV) * 1.26 - 0.13).bfloat16()
+    got = _gemm_nt(lib, A, B, L.EPI_DGELU, None, aux=gp16).float()
+    gp = gp16.float().double()
     want = (A.float() @ B.float().t()).double() * gp
     assert (got.double() - want).abs().max().item() < 2 ** -7 * want.abs().max().item()
 
@@ -93,7 +94,9 @@ def test_gemm_nt_large_shapes_take_the_256x256_kernel(lib, M, N, K, nv):
     aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     got = _gemm_nt(lib, A, B, L.EPI_GELU, bias, n_store=N, aux=aux).float()
     assert (got[:, :nv] - torch.nn.functional.gelu(ref)).abs().max().item() < 2 ** -8 * scale
-    assert (aux[:, :nv].float() - ref).abs().max().item() < 2 ** -8 * scale
+    xr = ref.double()
+    dref = (0.5 * (1 + torch.erf(xr / 2 ** 0.5)) + xr * torch.exp(-0.5 * xr * xr) / (2 * torch.pi) ** 0.5).float()
+    assert (aux[:, :nv].float() - dref).abs().max().item() < 2 ** -8 * 1.2          # aux = gelu'(pre-activation)
     # run-to-run determinism (a staging race would show up as rare differing tiles)
     first = _gemm_nt(lib, A, B, L.EPI_F32, bias, n_store=N)
     for _ in range(5):
