@@ -30,6 +30,7 @@ for p in (ROOT, os.path.join(ROOT, "kuzushiji-vision_amd")):
         sys.path.insert(0, p)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (block-scaled MFMA), same table
 
 
 def train_flops_per_image(cfg, T):
@@ -124,6 +125,9 @@ def main():
     ap.add_argument("--dec-layers", type=int, default=6, help="6 = BASELINE.json configs[1]; 12 = reference decoder")
     ap.add_argument("--encoder", choices=["vit_b", "vit_l"], default="vit_b",
                     help="vit_b = the benchmark (configs[1]/[2]); vit_l = configs[3]'s ViT-L/16 encoder (a side measurement)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="side measurement (configs[4], second half): the encoder's QKV / fc1 / fc2 forward GEMMs on e4m3 operands; "
+                         "NOT the benchmark line, which is bf16")
     ap.add_argument("--label-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
@@ -147,7 +151,7 @@ def main():
 
     with tempfile.TemporaryDirectory() as tmp:
         d = build_decoder_dir(os.path.join(tmp, "dec"), cfg)
-        model = TrOCRModel(cfg.encoder_config_dict(), d, device=dev, init_seed=42, load_tokenizer=False)
+        model = TrOCRModel(cfg.encoder_config_dict(), d, device=dev, init_seed=42, load_tokenizer=False, fp8=args.fp8)
     model._step_seed = 1_000_003 * rank            # per-rank dropout streams
     opt = model.configure_optimizers()
     model.train()
@@ -182,7 +186,7 @@ def main():
     nt_seen = int(lib.kzv_prof_seen(0))
     if events:                                             # untimed: one more step for the other kernel families
         L.check(lib.kzv_prof_sample(1), "prof_sample")
-        L.check(lib.kzv_prof_select((1 << 1) | (1 << 2) | (1 << 3)), "prof_select")
+        L.check(lib.kzv_prof_select((1 << 1) | (1 << 2) | (1 << 3) | (1 << 4)), "prof_select")
         L.check(lib.kzv_prof_enable(1, 16384), "prof_enable")
         stepper.step(batch, args.steps)
         barrier()
@@ -211,6 +215,11 @@ def main():
             m2, f2, n2 = collect(kind)
             others[name] = {"ms_per_step": m2, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0,
                             "launches_per_step": n2, "measured": "one extra step outside the timed region"}
+        if args.fp8:
+            m2, f2, n2 = collect(4)
+            others["gemm_nt_fp8_kernel"] = {"ms_per_step": m2, "TFLOP/s": (f2 / (m2 * 1e-3) / 1e12) if m2 > 0 else 0.0, "launches_per_step": n2,
+                                            "peak": PEAK_FP8_TFLOPS, "frac": (f2 / (m2 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS) if m2 > 0 else 0.0,
+                                            "measured": "one extra step outside the timed region"}
         DECPOS = (f"{t_act} of {T} computed: columns that are padding in every sample of the batch are skipped (exact: masked "
                   "keys, ignored targets); labels hold U{8..60} characters (BASELINE.md section 4)")
         # HBM-side bytes per launch come from rocprofv3 PMC passes (they cannot be collected from inside this process):
@@ -220,7 +229,7 @@ def main():
         import glob
         for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
             j = json.load(open(tj))
-            if j.get("source_sha16") == source_sha16() and args.batch == 256 and args.dec_layers == 6 and args.encoder == "vit_b":
+            if j.get("source_sha16") == source_sha16() and args.batch == 256 and args.dec_layers == 6 and args.encoder == "vit_b" and not args.fp8:
                 k = j["kernels"].get("gemm_nt_kernel<*>")
                 if k:
                     traffic, traffic_src = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], os.path.relpath(tj, ROOT)
@@ -228,7 +237,9 @@ def main():
         out = {
             "metric": "line-images/sec (train)", "value": imgs / dt, "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if not args.fp8 else "bf16 + e4m3 (encoder QKV/fc1/fc2 forward GEMMs): side measurement, not the benchmark line",
+            "data": "synthetic",
             "config": {"workload": f"TrOCR train step: {'ViT-B/16 (12L/768/12h/3072)' if args.encoder == 'vit_b' else 'ViT-L/16 (24L/1024/16h/4096)'} on 64x640 crops (S_e=161) + RoBERTa "
                                    f"decoder {args.dec_layers}L/256/4h/768, V=4300 one-char vocab, labels [B,{args.label_len}], "
                                    f"dropout 0.1, clip 1.0, RAdamScheduleFree; BASELINE.json configs[{(1 if world == 1 else 2) if args.encoder == 'vit_b' else 3}]",

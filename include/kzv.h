@@ -191,6 +191,41 @@ int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream);
  * M = batch GEMMs (one wave per 16x64 tile).  The per-op tests raise the threshold to check that kernel through this entry. */
 int kzv_set_rows_max_m(int n);
 
+/* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path on CDNA4"; beyond the reference, which has no fp8) ----
+ * C[M,N] = (A8[M,K] . B8[N,K]^T) * a_scale[m] * b_scale[n] (+bias) with the BF16 / GELU / RESID epilogue of kzv_gemm_nt.
+ * A8, B8: OCP e4m3 bytes; row m of A8 holds A[m,:] / a_scale[m] (likewise B8 / b_scale).  fp32 accumulate on the block-scaled
+ * MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): twice the bf16 MFMA rate.  K % 256 == 0.
+ * GELU only: when c8 is set, a second copy of C as e4m3, quantised with the per-tensor multiplier *c8_qscale (device scalar),
+ * feeds the next GEMM; max |C| is folded into *c8_amax (atomic max), from which the caller derives the next multiplier. */
+typedef struct kzv_gemm_nt_fp8_args {
+    const void* A; int64_t lda;       /* e4m3 [M,K] */
+    const void* B; int64_t ldb;       /* e4m3 [n_valid,K] */
+    const float* a_scale;             /* fp32 [M] */
+    const float* b_scale;             /* fp32 [n_valid] */
+    void* C; int64_t ldc;             /* bf16 (BF16, GELU) or fp32 (RESID) [M,N] */
+    const float* bias;                /* fp32 [n_valid] or NULL */
+    const float* resid; int64_t ldr;  /* RESID: fp32 [M,N] */
+    void* aux; int64_t ldaux;         /* GELU: bf16 gelu'(pre-activation) OUT */
+    void* c8; int64_t ldc8;           /* GELU: optional e4m3 [M,N] OUT */
+    const float* c8_qscale; float* c8_amax;
+    int32_t M, N, K, n_valid;
+    float drop_p; uint32_t drop_key;  /* RESID dropout on (acc*scales+bias) */
+} kzv_gemm_nt_fp8_args;
+int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void* stream);
+/* q[r,:] = e4m3(x[r,:] * 448 / amax_r), scale[r] = amax_r / 448 (1 for an all-zero row); cols % 4 == 0.  The quantiser of the
+ * weight copies (per output row) and, fused into LayerNorm, of its output rows. */
+int kzv_quant_rows_fp8(const float* x, int64_t rows, int64_t cols, void* q, float* scale, void* stream);
+/* kzv_layernorm_fwd that also writes the e4m3 copy of each output row and its scale. */
+int kzv_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8, float* y_scale,
+                          float* stats, int rows, int H, float eps, void* stream);
+/* Model switch (call before kzv_model_bind; encoder hidden and ffn must be multiples of 256): 1 = the encoder's QKV, fc1 and fc2
+ * forward GEMMs run on e4m3 operands (weights quantised per output row at kzv_model_sync_weights; LayerNorm outputs per token
+ * row; GELU outputs per tensor with the previous forward's amax); everything else, backward included, stays bf16. */
+int kzv_set_fp8(kzv_model* m, int mode);
+int kzv_get_fp8(const kzv_model* m);
+/* Parity hook: the per-tensor multipliers the last forward quantised each encoder layer's GELU output with -> d_out[enc_layers]. */
+int kzv_fp8_act_scales(const kzv_model* m, float* d_out, void* stream);
+
 /* OUT[N,K] (+)= P[Mtok,N]^T . Q[Mtok,K]   (weight gradient; fp32 atomics over token splits) */
 typedef struct kzv_gemm_tn_args {
     const void* P; int64_t ldp;       /* bf16 [Mtok, N] */
@@ -229,7 +264,7 @@ int kzv_attn_bwd(const kzv_attn_args* a, void* stream);
 
 /* ------------------------------------------------------------- measurement hooks (bench.py roofline leg)
  * When enabled, every launch of the hot kernels is bracketed by HIP events on its own stream.
- * kind: 0 gemm_nt, 1 gemm_tn, 2 attn_fwd, 3 attn_bwd.  work = algorithmic FLOPs (2*M*N*K; 4*B*h*Sq*Sk*64 /
+ * kind: 0 gemm_nt, 1 gemm_tn, 2 attn_fwd, 3 attn_bwd, 4 gemm_nt_fp8.  work = algorithmic FLOPs (2*M*N*K; 4*B*h*Sq*Sk*64 /
  * 10*B*h*Sq*Sk*64 for attention fwd / bwd).  Collect after synchronising the stream.
  * kzv_prof_select restricts recording to the kinds in `kind_mask` (bit k = kind k; default all): every bracketed
  * launch costs ~2 us of stream time, so the timed region records only the kernel it reports. */

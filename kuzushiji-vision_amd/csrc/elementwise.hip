@@ -292,6 +292,57 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const KzvCastDesc* __
     }
 }
 
+// ------------------------------------------------------------------------------------------- fp8 path
+// One wave per row: amax, then e4m3(x * 448 / amax) and scale = amax / 448 (a zero row keeps scale 1).  `desc` == nullptr:
+// the single matrix `one`; otherwise the row -> matrix table (row0 ascending), binary-searched like cast_weights.
+__global__ __launch_bounds__(256) void quant_rows_kernel(const KzvQuantDesc* __restrict__ desc, int ndesc, const KzvQuantDesc one, int total_rows) {
+    const int lane = threadIdx.x & 63;
+    const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grow >= total_rows) return;
+    KzvQuantDesc d = one;
+    if (desc) {
+        int lo = 0, hi = ndesc - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (desc[mid].row0 <= grow) lo = mid; else hi = mid - 1;
+        }
+        d = desc[lo];
+    }
+    const int r = grow - d.row0;
+    const float4* x = (const float4*)(d.src + (int64_t)r * d.cols);
+    const int nc = d.cols >> 2;                       // cols % 4 == 0 is checked on the host
+    float amax = 0.f;
+    for (int i = lane; i < nc; i += 64) {
+        const float4 v = x[i];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    amax = wave_max(amax);
+    const float qs = amax > 0.f ? KZV_FP8_MAX / amax : 1.f;
+    if (lane == 0) d.scale[r] = amax > 0.f ? amax / KZV_FP8_MAX : 1.f;
+    unsigned* q = (unsigned*)(d.dst + (int64_t)r * d.cols);
+    for (int i = lane; i < nc; i += 64) {
+        const float4 v = x[i];                        // second read of a row this wave just streamed: L2 / L1 hit
+        q[i] = pack_fp8x4(v.x * qs, v.y * qs, v.z * qs, v.w * qs);
+    }
+}
+
+__global__ void fp8_roll_kernel(float* qscale, float* amax, float* row_scales, int sites, int rows) {
+    const int site = blockIdx.y;
+    float q = qscale[site];
+    const float a = amax[site];
+    if (a > 0.f) q = exp2f(floorf(log2f(KZV_FP8_MAX / a)) - 1.f);
+    const float inv = 1.f / q;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) row_scales[(int64_t)site * rows + r] = inv;
+}
+// publishing the new multiplier in the kernel that still reads the old one would race across blocks: a second tiny kernel
+__global__ void fp8_roll_publish_kernel(float* qscale, float* amax, int sites) {
+    const int site = blockIdx.x * blockDim.x + threadIdx.x;
+    if (site >= sites) return;
+    const float a = amax[site];
+    if (a > 0.f) qscale[site] = exp2f(floorf(log2f(KZV_FP8_MAX / a)) - 1.f);
+    amax[site] = 0.f;
+}
+
 // debug / parity: the multiplier every fused dropout applies to element index row * ld + col
 __global__ void dropout_mask_kernel(float* __restrict__ out, int64_t rows, int64_t cols, int64_t ld, unsigned thr16, float inv_keep, unsigned key) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,6 +430,27 @@ int kzv_copy_logits(const float* logits, int64_t ldl, float* out, int rows, int 
 int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s) {
     hipLaunchKernelGGL(cast_weights_kernel, dim3(total_tiles), dim3(256), 0, s, d_desc, ndesc);
     return kzv_check_launch("cast_weights");
+}
+
+int kzv_quant_rows(const KzvQuantDesc* d_desc, int ndesc, int total_rows, hipStream_t s) {
+    if (!d_desc || ndesc <= 0 || total_rows <= 0) return kzv_fail(KZV_E_ARG, "quant_rows: empty table");
+    hipLaunchKernelGGL(quant_rows_kernel, dim3((total_rows + 3) / 4), dim3(256), 0, s, d_desc, ndesc, KzvQuantDesc{}, total_rows);
+    return kzv_check_launch("quant_rows");
+}
+
+extern "C" int kzv_quant_rows_fp8(const float* x, int64_t rows, int64_t cols, void* q, float* scale, void* stream) {
+    if (!x || !q || !scale || rows <= 0 || cols <= 0 || rows > 0x7fffffff) return kzv_fail(KZV_E_ARG, "quant_rows_fp8: null/empty");
+    if (cols % 4 || ((uintptr_t)x & 15) || ((uintptr_t)q & 3)) return kzv_fail(KZV_E_ARG, "quant_rows_fp8: cols must be a multiple of 4, x 16-byte aligned");
+    const KzvQuantDesc one{x, (unsigned char*)q, scale, (int)rows, (int)cols, 0};
+    hipLaunchKernelGGL(quant_rows_kernel, dim3(((int)rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const KzvQuantDesc*)nullptr, 0, one, (int)rows);
+    return kzv_check_launch("quant_rows_fp8");
+}
+
+int kzv_fp8_roll(float* qscale, float* amax, float* row_scales, int sites, int rows, hipStream_t s) {
+    if (!qscale || !amax || !row_scales || sites <= 0 || rows <= 0) return kzv_fail(KZV_E_ARG, "fp8_roll: null/empty");
+    hipLaunchKernelGGL(fp8_roll_kernel, dim3(nblk(rows, 256) < 64 ? nblk(rows, 256) : 64, sites), dim3(256), 0, s, qscale, amax, row_scales, sites, rows);
+    hipLaunchKernelGGL(fp8_roll_publish_kernel, dim3(nblk(sites, 64)), dim3(64), 0, s, qscale, amax, sites);
+    return kzv_check_launch("fp8_roll");
 }
 
 extern "C" int kzv_debug_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t ld_index, float* d_out, void* stream) {

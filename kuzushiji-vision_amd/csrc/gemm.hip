@@ -410,7 +410,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return kzv_fail(KZV_E_ARG, "gemm_nt: operands must be 16-byte aligned");
     if (epilogue == KZV_EPI_RESID && (!a->resid || a->ldr % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt: RESID needs resid, ldr%4==0");
     if ((epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_DGELU || epilogue == KZV_EPI_GELU_F32) && (!a->aux || a->ldaux % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt: GELU/DGELU need aux");
-    NtParams p;
+    NtParams p{};
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.C = a->C; p.bias = a->bias; p.resid = a->resid;
     p.aux = (bf16_t*)a->aux; p.zero16 = kzv_zero_page();
     if (!p.zero16) return kzv_fail(KZV_E_HIP, "gemm_nt: zero page unavailable");
@@ -452,6 +452,35 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
 #undef KZV_NT_VARIANT
 #undef KZV_NT_CASE
     return kzv_check_launch("gemm_nt");
+}
+
+// fp8 (e4m3) operands with per-row scales, block-scaled MFMA at twice the bf16 rate (gemm_nt256p.hip).
+extern "C" int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || !a->a_scale || !a->b_scale) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: null operand or scale");
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: empty shape");
+    if (a->K % 256) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: K must be a multiple of 256");
+    if (a->N % 4 || a->ldc % 4) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: N and ldc must be multiples of 4");
+    if (a->lda % 16 || a->ldb % 16) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: lda/ldb must be multiples of 16 (16-byte rows)");
+    if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: operands must be 16-byte aligned");
+    if (epilogue != KZV_EPI_BF16 && epilogue != KZV_EPI_GELU && epilogue != KZV_EPI_RESID) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: epilogue must be BF16, GELU or RESID");
+    if (epilogue == KZV_EPI_RESID && (!a->resid || a->ldr % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: RESID needs resid, ldr%4==0");
+    if (epilogue == KZV_EPI_GELU && (!a->aux || a->ldaux % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: GELU needs aux");
+    if (epilogue == KZV_EPI_GELU && a->c8 && (!a->c8_qscale || !a->c8_amax || a->ldc8 % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: c8 needs c8_qscale, c8_amax, ldc8%4==0");
+    NtParams p{};
+    p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.C = a->C; p.bias = a->bias; p.resid = a->resid;
+    p.aux = (bf16_t*)a->aux; p.zero16 = kzv_zero_page();
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldaux = a->ldaux;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
+    kzv_drop_params(a->drop_p, &p.drop_thr16, &p.drop_inv_keep);
+    p.drop_key = a->drop_key;
+    p.strip = kzv_nt_strip();
+    p.a_scale = a->a_scale; p.b_scale = a->b_scale;
+    p.c8 = (unsigned char*)a->c8; p.ldc8 = a->ldc8; p.c8_qscale = a->c8_qscale; p.c8_amax = a->c8_amax;
+    hipStream_t s = (hipStream_t)stream;
+    KzvProfScope prof(4, 2.0 * a->M * p.n_valid * a->K, s);
+    const int rc = kzv_nt256p_fp8_launch(p, epilogue, s);
+    if (rc != KZV_OK) return rc;
+    return kzv_check_launch("gemm_nt_fp8");
 }
 
 static int tn_fill(const kzv_gemm_tn_args* a, TnParams& p) {

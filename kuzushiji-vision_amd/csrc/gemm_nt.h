@@ -11,6 +11,12 @@ struct NtParams {
     int M, N, K, n_valid;
     unsigned drop_thr16; float drop_inv_keep; unsigned drop_key;
     int strip;          // tile-walk strip width of the 256x256 kernels (nt_tile_coords)
+    // fp8 operands (kzv_nt256p_fp8_launch only; A and B are e4m3 bytes, lda / ldb in elements = bytes):
+    // C = (acc * a_scale[m] * b_scale[n]) + bias, then the epilogue as usual
+    const float* a_scale; const float* b_scale;
+    // GELU epilogue of the fp8 kernel: a second copy of C as e4m3 (the next GEMM's A operand), quantised with the
+    // per-tensor multiplier *c8_qscale; the largest |C| seen is folded into *c8_amax (next step's multiplier)
+    unsigned char* c8; int64_t ldc8; const float* c8_qscale; float* c8_amax;
 };
 
 // One thread finishes 4 consecutive columns n0..n0+3 of output row m: v = accumulator + bias on entry;
@@ -42,6 +48,8 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
         nt_st((uint2*)(p.aux + (int64_t)m * p.ldaux + n0), make_uint2(pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])));
         if (EPI == KZV_EPI_GELU) nt_st((uint2*)((bf16_t*)p.C + (int64_t)m * p.ldc + n0), make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])));
         else nt_st((float4*)((float*)p.C + (int64_t)m * p.ldc + n0), make_float4(y[0], y[1], y[2], y[3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = y[r];          // the fp8 kernel quantises the activation once more from here
     } else if (EPI == KZV_EPI_RESID) {
         if (p.drop_thr16) {
             const unsigned e = (unsigned)m * (unsigned)p.N + (unsigned)n0;
@@ -81,6 +89,9 @@ int kzv_nt_strip();      // KZV_NT_STRIP (default 3)
 int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);
 // gemm_nt256p.hip (persistent variant of the same schedule): same contract.
 int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s);
+// fp8 (e4m3) operands on the block-scaled MFMA, same persistent schedule (gemm_nt256p.hip); epilogues BF16, GELU, RESID.
+// Returns KZV_OK or an error: there is no other fp8 kernel to fall back to.
+int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s);
 // gemm_rows.hip (few rows: one wave per 16x64 tile, operands straight from L2): same contract.  Taken inside a KzvRowsScope
 // (the generation step, model.cpp) for M <= 4096, elsewhere only below kzv_set_rows_max_m (default 0: never), so that the
 // training step and its parity tests keep running the tiled kernels at every size.

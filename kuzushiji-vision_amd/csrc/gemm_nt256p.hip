@@ -17,11 +17,20 @@
 // outstanding every operation issued after that load: the usual 8 (four half-tiles) plus the D loads/stores of the
 // drain.  D is only credited for interior tiles, where every row and column is stored (an edge tile skips some
 // stores; crediting too few is merely conservative, crediting too many would be a race).
+//
+// F8 = true: the same schedule on e4m3 operands.  A K-tile is still 128 BYTES per row (128 fp8 elements instead of 64 bf16),
+// so the LDS ring, the LDS-DMA pieces, the swizzle and every ds_read_b128 are byte-for-byte those of the bf16 kernel; the two
+// 16-byte fragments a lane reads per operand row (K-chunks g and 4+g) are the 32 bytes of ONE block-scaled
+// v_mfma_scale_f32_16x16x128_f8f6f4 (scales = 2^0) in place of two v_mfma_f32_16x16x32_bf16.  The instruction sums over its
+// 128 k-positions whichever position a byte sits in, and A and B are permuted alike, so no re-ordering is needed.  Same MFMA
+// cycles per K-tile, half as many K-tiles: twice the bf16 rate in the main loop.  The drain multiplies each accumulator by
+// a_scale[row] * b_scale[column] (per-row quantisation of both operands) before the bias.
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
 #include "gemm_nt.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -33,6 +42,13 @@ constexpr int KA0 = 0, KB0 = 2;             // half-tile slots of a ring buffer:
 
 __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// D += A(e4m3, 16x128) . B(e4m3, 128x16) with unit block scales.  Inline asm with the accumulator TIED to the result: through the
+// builtin hipcc gives every scaled MFMA a fresh result tuple (no in-place form), which with 128 accumulator registers spills
+// half of them.  hipcc pads no hazards around asm: the caller keeps VALU reads of the accumulators >= 18 wait states behind the
+// last MFMA (s_nop before the drain); operands come from LDS reads, which the compiler still waits for (they are asm inputs).
+__device__ __forceinline__ void mfma_f8(f32x4& acc, const i32x8& a, const i32x8& b, int one_scale) {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(one_scale));
 }
 template <int N> __device__ __forceinline__ void vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -47,8 +63,9 @@ template <int N> __device__ __forceinline__ void vmcnt() {
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
 // VMEM operations one wave issues while draining an interior tile (32 four-column groups per lane)
-template <int EPI> constexpr int drain_ops() {
-    return (EPI == KZV_EPI_BF16 || EPI == KZV_EPI_F32) ? 32 : 64;   // GELU*: two stores; RESID/DGELU: load + store
+template <int EPI, bool F8> constexpr int drain_ops() {
+    // GELU*: two stores; RESID/DGELU: load + store; fp8: + the row scale (and the e4m3 copy of a GELU output)
+    return ((EPI == KZV_EPI_BF16 || EPI == KZV_EPI_F32) ? 32 : 64) + (F8 ? (EPI == KZV_EPI_GELU ? 64 : 32) : 0);
 }
 
 struct TileSrc {            // where the next half-tiles of one half index (h) come from
@@ -57,8 +74,9 @@ struct TileSrc {            // where the next half-tiles of one half index (h) c
     int kt, seq; bool valid;
 };
 
-template <int EPI>
+template <int EPI, bool F8>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN, const int strip) {
+    constexpr int ES = F8 ? 1 : 2;                 // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +85,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     const int G = gridDim.x;
     // blocks land on XCD (blockIdx % 8): give each XCD a contiguous run of every step's tiles (shared A row panels)
     const int vblk = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int nk = p.K / 64;                       // even, >= 2 (checked by the launcher)
+    const int nk = p.K * ES / 128;                 // K-tiles of 128 bytes per row: even, >= 2 (checked by the launcher)
 
     auto set_tile = [&](TileSrc& s, int seq, int h) {
         s.seq = seq; s.kt = 0;
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
         int tm, tn;
         nt_tile_coords(idc, tiles / tilesN, tilesN, strip, tm, tn);
         tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
-        s.a = (const char*)(p.A + (int64_t)tm * 256 * p.lda);
+        s.a = (const char*)p.A + (int64_t)tm * 256 * p.lda * ES;
         s.b = (const char*)p.B;
         int ln = lane;
         asm volatile("" : "+v"(ln));       // recompute the lane terms here: hoisted, they would live (and spill) across the K loop
@@ -87,10 +105,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
             const unsigned cb = (unsigned)(((ln & 7) ^ (r & 7)) * 16);
             int arow = (r >> 6) * 128 + h * 64 + (r & 63);
             arow = min(tm * 256 + arow, p.M - 1) - tm * 256;            // rows beyond M: clamp (never stored)
-            s.va[j] = (unsigned)arow * (unsigned)(p.lda * 2) + cb;
+            s.va[j] = (unsigned)arow * (unsigned)(p.lda * ES) + cb;
             int bcol = (r >> 5) * 64 + h * 32 + (r & 31);
             bcol = min(tn * 256 + bcol, p.n_valid - 1);                 // columns beyond n_valid: clamp (stored as 0)
-            s.vb[j] = (unsigned)bcol * (unsigned)(p.ldb * 2) + cb;
+            s.vb[j] = (unsigned)bcol * (unsigned)(p.ldb * ES) + cb;
         }
     };
     auto advance = [&](TileSrc& s, int h) {
@@ -120,37 +138,55 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     const int sw = l15 & 7;
     const int slot0 = (g ^ sw) << 4, slot1 = ((4 + g) ^ sw) << 4;
     const int a_off = (wr * 64 + l15) * 128, b_off = (wc * 32 + l15) * 128;
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    // fragments: bf16 = two 16-byte K-chunks per row used by two MFMAs; fp8 = the same two chunks as ONE 32-byte operand, kept
+    // as an 8-register value from the read on (joined at each use, hipcc kept both forms alive and spilled the accumulators)
+    struct FragBf { bf16x8 k[2]; };
+    using Frag = std::conditional_t<F8, i32x8, FragBf>;
+    Frag fa[4], fb0[2], fb1[2];
+    int one_scale = 0x7f7f7f7f;                  // E8M0 2^0 in every byte (whichever one op_sel picks)
+    asm volatile("" : "+v"(one_scale));          // a VGPR, set once (far from the first MFMA that reads it)
+    auto rd = [&](const char* q) {
+        if constexpr (F8) {
+            const i32x4 lo = *(const i32x4*)(q + slot0), hi = *(const i32x4*)(q + slot1);
+            return (i32x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+            FragBf f;
+            f.k[0] = *(const bf16x8*)(q + slot0); f.k[1] = *(const bf16x8*)(q + slot1);
+            return f;
+        }
+    };
     auto readA = [&](int buf, int mh) {
         const char* b = smem + buf * BUF_BYTES + (KA0 + mh) * HT_BYTES + a_off;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i][0] = *(const bf16x8*)(b + i * 2048 + slot0);
-            fa[i][1] = *(const bf16x8*)(b + i * 2048 + slot1);
-        }
+        for (int i = 0; i < 4; ++i) fa[i] = rd(b + i * 2048);
     };
-    auto readB = [&](int buf, int nh, bf16x8 (&fb)[2][2]) {
+    auto readB = [&](int buf, int nh, Frag (&fb)[2]) {
         const char* b = smem + buf * BUF_BYTES + (KB0 + nh) * HT_BYTES + b_off;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            fb[j][0] = *(const bf16x8*)(b + j * 2048 + slot0);
-            fb[j][1] = *(const bf16x8*)(b + j * 2048 + slot1);
-        }
+        for (int j = 0; j < 2; ++j) fb[j] = rd(b + j * 2048);
     };
-    auto mma = [&](int mh, int nh, const bf16x8 (&fb)[2][2]) {
+    auto mm = [&](int mh, int nh, const Frag (&fb)[2]) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+        if constexpr (F8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kh], fa[i][kh], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+                    mfma_f8(acc[mh * 4 + i][nh * 2 + j], fb[j], fa[i], one_scale);
+        } else {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j].k[kh], fa[i].k[kh], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
     TileSrc s1, s2;                    // s1 feeds A-h1/B-h1 of stream K-tile u+1, s2 feeds A-h0/B-h0 of K-tile u+2
-    constexpr int D = drain_ops<EPI>();
+    constexpr int D = drain_ops<EPI, F8>();
     constexpr int W8 = cmin(63, 8 + D);
 
     // One K-tile of the stream = four phases (gemm_nt256.hip).  e1 / e2: stream K-tiles u+1 / u+2 exist.
@@ -162,26 +198,26 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
         readA(BUF, 0); readB(BUF, 0, fb0);
         if (e1) { stageB(s1, BUF ^ 1, 1); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); } else vmcnt<2>();
         __builtin_amdgcn_s_barrier();
-        mma(0, 0, fb0);
+        mm(0, 0, fb0);
         __builtin_amdgcn_s_barrier();
         // p2
         readB(BUF, 1, fb1);
         if (e1) { stageA(s1, BUF ^ 1, 1); if (after_drain) vmcnt<W8>(); else vmcnt<8>(); } else vmcnt<0>();
         advance(s1, 1);
         __builtin_amdgcn_s_barrier();
-        mma(0, 1, fb1);
+        mm(0, 1, fb1);
         __builtin_amdgcn_s_barrier();
         // p3
         readA(BUF, 1);
         if (e2) stageA(s2, BUF, 0);
         __builtin_amdgcn_s_barrier();
-        mma(1, 1, fb1);
+        mm(1, 1, fb1);
         __builtin_amdgcn_s_barrier();
         // p4
         if (e2) { stageB(s2, BUF, 0); vmcnt<8>(); advance(s2, 0); }
         else if (e1) vmcnt<4>();                      // tail, or refills deferred past the drain: only p1/p2's are newer
         __builtin_amdgcn_s_barrier();
-        mma(1, 0, fb0);
+        mm(1, 0, fb0);
         __builtin_amdgcn_s_barrier();
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -208,22 +244,38 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
                 for (int r = 0; r < 4; ++r) if (nv[r]) b4[r] = p.bias[n0 + r];
             }
         }
-        auto block_loads = [&](int i, float4 (&r4)[4], uint2 (&u2)[4]) {
+        // fp8: accumulator * a_scale[row] * b_scale[column]; the GELU output's e4m3 copy uses the per-tensor multiplier qs
+        float sw4[4] = {1.f, 1.f, 1.f, 1.f};
+        float qs = 0.f, amax = 0.f;
+        if constexpr (F8) {
+            if constexpr (interior) { const float4 t = *(const float4*)(p.b_scale + n0); sw4[0] = t.x; sw4[1] = t.y; sw4[2] = t.z; sw4[3] = t.w; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (nv[r]) sw4[r] = p.b_scale[n0 + r];
+            }
+            if (EPI == KZV_EPI_GELU && p.c8) qs = *p.c8_qscale;
+        }
+        auto emit8 = [&](int m, const float (&y)[4]) {        // e4m3 copy of a finished GELU row group (plain stores: L2 merges the 64-B pieces)
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+            *(unsigned*)(p.c8 + (int64_t)m * p.ldc8 + n0) = pack_fp8x4(y[0] * qs, y[1] * qs, y[2] * qs, y[3] * qs);
+        };
+        auto block_loads = [&](int i, float4 (&r4)[4], uint2 (&u2)[4], float (&sa)[4]) {
             const int m0 = tm * 256 + wr * 128 + i * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + q * 4 + prow;
                 if (EPI == KZV_EPI_RESID) r4[q] = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
                 if (EPI == KZV_EPI_DGELU) u2[q] = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
+                if (F8) sa[q] = p.a_scale[m];
             }
         };
         // interior tiles: branch-free (counted vmcnt; see gemm_nt256.hip), the residual / pre-activation loads running
         // LOOK row blocks ahead of their use; edge tiles: guarded, row by row
-        constexpr int LOOK = 4;
-        float4 r4[8][4]; uint2 u2[8][4];
+        constexpr int LOOK = (F8 && EPI == KZV_EPI_RESID) ? 3 : 4;     // fp8 + residual: one block less in flight (the row scales need registers too)
+        float4 r4[8][4]; uint2 u2[8][4]; float sa[8][4];
         if constexpr (interior) {
 #pragma unroll
-            for (int i = 0; i < LOOK; ++i) block_loads(i, r4[i], u2[i]);
+            for (int i = 0; i < LOOK; ++i) block_loads(i, r4[i], u2[i], sa[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                         // accumulator row block i: tile rows wr*128 + i*16 .. +15
@@ -238,10 +290,13 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
                 for (int q = 0; q < 4; ++q) {
                     const int row = q * 4 + prow;
                     const f32x4 a4 = *(const f32x4*)(patch + row * 64 + ((pchunk ^ row) << 2));
-                    float v[4] = {a4[0] + b4[0], a4[1] + b4[1], a4[2] + b4[2], a4[3] + b4[3]};
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = F8 ? fmaf(a4[r], sa[i][q] * sw4[r], b4[r]) : a4[r] + b4[r];
                     nt_emit<EPI>(p, m0 + row, n0, v, r4[i][q], u2[i][q]);
+                    if constexpr (F8 && EPI == KZV_EPI_GELU) { if (p.c8) emit8(m0 + row, v); }
                 }
-                if (i + LOOK < 8) block_loads(i + LOOK, r4[i + LOOK], u2[i + LOOK]);
+                if (i + LOOK < 8) block_loads(i + LOOK, r4[i + LOOK], u2[i + LOOK], sa[i + LOOK]);
             } else {
 #pragma unroll 1
                 for (int q = 0; q < 4; ++q) {
@@ -252,12 +307,21 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
                         float4 e4 = make_float4(0, 0, 0, 0); uint2 eu = make_uint2(0, 0);
                         if (EPI == KZV_EPI_RESID) e4 = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
                         if (EPI == KZV_EPI_DGELU) eu = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
+                        const float sr = F8 ? p.a_scale[m] : 1.f;
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = nv[r] ? a4[r] + b4[r] : 0.f;
+                        for (int r = 0; r < 4; ++r) v[r] = nv[r] ? (F8 ? fmaf(a4[r], sr * sw4[r], b4[r]) : a4[r] + b4[r]) : 0.f;
                         nt_emit<EPI>(p, m, n0, v, e4, eu);
+                        if constexpr (F8 && EPI == KZV_EPI_GELU) { if (p.c8) emit8(m, v); }
                     }
                 }
+            }
+        }
+        if constexpr (F8 && EPI == KZV_EPI_GELU) {
+            // one atomic per wave at most, and none once the running maximum is above this tile's (floats >= 0 order as integers)
+            if (p.c8) {
+                amax = wave_max(amax);
+                if (ln == 0 && amax > *(volatile float*)p.c8_amax) atomicMax((unsigned*)p.c8_amax, __float_as_uint(amax));
             }
         }
     };
@@ -297,6 +361,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
             ktile(I1{}, false, kt + 2 >= nk);        // last K-tile of the tile: its A-h0/B-h0 refills wait for the drain
         }
         KZV_STAMP();
+        if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // the asm MFMAs' results are read next (mfma_f8)
         credit = tm * 256 + 256 <= p.M && tn * 256 + 256 <= p.n_valid;     // interior tile (n_valid <= N)
         if (credit) drain(tm, tn, std::true_type{}); else drain(tm, tn, std::false_type{});
         // the refills deferred by the last K-tile (stream K-tile u+2 -> ring buffer 1): issued only now, so that the
@@ -346,8 +411,8 @@ int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s) {
 #define KZV_NT256P_CASE(E)                                                                                          \
     case E: {                                                                                                       \
         static bool attr_done = false;                                                                              \
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<E>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN, kzv_nt_strip());         \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<E, false>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN, kzv_nt_strip());         \
     } break;
     switch (epilogue) {
         KZV_NT256P_CASE(KZV_EPI_BF16) KZV_NT256P_CASE(KZV_EPI_F32) KZV_NT256P_CASE(KZV_EPI_GELU)
@@ -356,4 +421,25 @@ int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s) {
     }
 #undef KZV_NT256P_CASE
     return 1;
+}
+
+int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s) {
+    const int tilesN = (p.N + 255) / 256;
+    const int tiles = ((p.M + 255) / 256) * tilesN;
+    if (p.K < 256 || p.K % 256) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: K must be a multiple of 256 (an even number of 128-byte K-tiles)");
+    if ((uint64_t)256 * (uint64_t)p.lda > 0xffffffffull || (uint64_t)p.n_valid * (uint64_t)p.ldb > 0xffffffffull)
+        return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: operand panel beyond the 32-bit LDS-DMA offsets");
+    const int grid = tiles < device_cus() ? tiles : device_cus();
+#define KZV_NT256P8_CASE(E)                                                                                         \
+    case E: {                                                                                                       \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; } \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<E, true>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN, kzv_nt_strip());   \
+    } break;
+    switch (epilogue) {
+        KZV_NT256P8_CASE(KZV_EPI_BF16) KZV_NT256P8_CASE(KZV_EPI_GELU) KZV_NT256P8_CASE(KZV_EPI_RESID)
+        default: return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: epilogue must be BF16, GELU or RESID");
+    }
+#undef KZV_NT256P8_CASE
+    return KZV_OK;
 }

@@ -21,6 +21,20 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)(pack_bf2(x, 0.f) & 0xffffu); }
 
+// ---- fp8 (OCP e4m3fn: the gfx950 format) ---------------------------------------
+// Four floats -> four e4m3 bytes (byte 0 = a), round-to-nearest-even (v_cvt_pk_fp8_f32), clamped to the largest
+// finite value first so that an out-of-range input saturates whatever the conversion's overflow mode is.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;    // one scaled-MFMA 16x16x128 fp8 A/B fragment (8 VGPRs)
+#define KZV_FP8_MAX 448.f
+__device__ __forceinline__ float fp8_clamp(float x) { return __builtin_amdgcn_fmed3f(x, -KZV_FP8_MAX, KZV_FP8_MAX); }
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    unsigned r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(a), fp8_clamp(b), r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(c), fp8_clamp(d), r, true);
+    return r;
+}
+
 // ---- wave64 reductions ------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

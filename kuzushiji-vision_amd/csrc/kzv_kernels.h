@@ -6,7 +6,8 @@
 
 // layernorm.hip
 int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* stats,
-                  int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s);
+                  int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s,
+                  void* y8 = nullptr, float* y8_scale = nullptr);    // y8: e4m3 copy with one scale per row (fp8 path)
 int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
                   int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
                   float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16 = nullptr, float out_drop_p = 0.f,
@@ -36,6 +37,14 @@ struct KzvCastDesc {         // one 2-D fp32 weight -> bf16 copy (+ optional tra
     int rows, cols; int64_t ldT; int tile0, tiles_c;
 };
 int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s);
+
+// fp8 path: fp32 rows -> e4m3 rows quantised by their own largest |x| (dst ~ x * 448 / amax, scale = amax / 448)
+struct KzvQuantDesc { const float* src; unsigned char* dst; float* scale; int rows, cols, row0; };
+int kzv_quant_rows(const KzvQuantDesc* d_desc, int ndesc, int total_rows, hipStream_t s);
+// fp8 path, once per forward: next multiplier of every per-tensor activation site from the largest |value| the last
+// forward saw (power of two, one binade of headroom; unchanged while amax == 0), amax reset, and the dequantisation
+// factor 1 / qscale[site] broadcast to the `rows` entries of that site's row-scale array (what the GEMM reads)
+int kzv_fp8_roll(float* qscale, float* amax, float* row_scales, int sites, int rows, hipStream_t s);
 
 // gemm.hip: n independent weight gradients in one grid
 struct kzv_gemm_tn_args;

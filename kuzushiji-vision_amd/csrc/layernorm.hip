@@ -25,9 +25,10 @@ struct LnFwd {
     const float* x; const float* gamma; const float* beta; bf16_t* y16; float* y32; float* stats;
     int rows, H, seq, drop_first; float eps;
     unsigned thr16; float inv_keep; unsigned key;
+    unsigned char* y8; float* y8_scale;      // F8: e4m3 copy of the output row, quantised by its own largest |y| (y ~ y8 * y8_scale[row])
 };
 
-template <int NC>
+template <int NC, bool F8>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
         if (row % p.seq == 0) return;
         orow = row - row / p.seq - 1;
     }
+    float amax = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int i = lane + c * 64;
@@ -73,6 +75,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
             }
             if (p.y16) ((uint2*)(p.y16 + (int64_t)orow * p.H))[i] = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
             if (p.y32) ((float4*)(p.y32 + (int64_t)orow * p.H))[i] = make_float4(o0, o1, o2, o3);
+            if (F8) {
+                v[c] = make_float4(o0, o1, o2, o3);
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))));
+            }
+        }
+    }
+    if (F8) {
+        amax = wave_max(amax);
+        const float qs = amax > 0.f ? KZV_FP8_MAX / amax : 1.f;
+        if (lane == 0) p.y8_scale[orow] = amax > 0.f ? amax / KZV_FP8_MAX : 1.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int i = lane + c * 64;
+            if (i < nc) ((unsigned*)(p.y8 + (int64_t)orow * p.H))[i] = pack_fp8x4(v[c].x * qs, v[c].y * qs, v[c].z * qs, v[c].w * qs);
         }
     }
 }
@@ -323,18 +339,24 @@ float* ln_partials() {          // one zeroed [LN_SLOTS][2][2048] buffer per pro
 }  // namespace
 
 int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* stats,
-                  int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s) {
+                  int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s,
+                  void* y8, float* y8_scale) {
     if (!x || !gamma || !beta || rows <= 0) return kzv_fail(KZV_E_ARG, "layernorm_fwd: null/empty");
     if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
-    LnFwd p{x, gamma, beta, (bf16_t*)y16, y32, stats, rows, H, seq > 0 ? seq : 1, drop_first, eps, 0, 1.f, drop_key};
+    if ((y8 != nullptr) != (y8_scale != nullptr)) return kzv_fail(KZV_E_ARG, "layernorm_fwd: the fp8 copy needs both y8 and y8_scale");
+    LnFwd p{x, gamma, beta, (bf16_t*)y16, y32, stats, rows, H, seq > 0 ? seq : 1, drop_first, eps, 0, 1.f, drop_key,
+            (unsigned char*)y8, y8_scale};
     kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
     const int ncl = (H / 4 + 63) / 64;
     const dim3 grid((rows + 3) / 4);
-    if (ncl <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, p);
-    else if (ncl == 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, p);
-    else if (ncl == 3) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, s, p);
-    else if (ncl == 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, s, p);
+#define KZV_LN_FWD(NC) do { if (y8) hipLaunchKernelGGL((ln_fwd_kernel<NC, true>), grid, dim3(256), 0, s, p);          \
+                            else hipLaunchKernelGGL((ln_fwd_kernel<NC, false>), grid, dim3(256), 0, s, p); } while (0)
+    if (ncl <= 1) KZV_LN_FWD(1);
+    else if (ncl == 2) KZV_LN_FWD(2);
+    else if (ncl == 3) KZV_LN_FWD(3);
+    else if (ncl == 4) KZV_LN_FWD(4);
+    else KZV_LN_FWD(8);
+#undef KZV_LN_FWD
     return kzv_check_launch("layernorm_fwd");
 }
 
@@ -377,6 +399,12 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
 extern "C" int kzv_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                                  float* stats, int rows, int H, float eps, void* stream) {
     return kzv_ln_fwd_ex(x, gamma, beta, y_bf16, y_f32, stats, rows, H, eps, 1, 0, 0.f, 0, (hipStream_t)stream);
+}
+
+extern "C" int kzv_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8, float* y_scale,
+                                     float* stats, int rows, int H, float eps, void* stream) {
+    if (!y_fp8 || !y_scale) return kzv_fail(KZV_E_ARG, "layernorm_fwd_fp8: y_fp8 and y_scale are required");
+    return kzv_ln_fwd_ex(x, gamma, beta, y_bf16, nullptr, stats, rows, H, eps, 1, 0, 0.f, 0, (hipStream_t)stream, y_fp8, y_scale);
 }
 
 extern "C" int kzv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma,

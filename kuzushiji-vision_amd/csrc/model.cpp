@@ -26,6 +26,7 @@ inline int64_t align_up(int64_t n, int64_t a) { return (n + a - 1) / a * a; }
 struct EncLayerP { int64_t ln1w, ln1b, qkvw, qkvb, ow, ob, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b; };
 struct DecLayerP { int64_t qkvw, qkvb, ow, ob, ln1w, ln1b, cqw, cqb, cow, cob, ln2w, ln2b, fc1w, fc1b, fc2w, fc2b, ln3w, ln3b; };
 struct W16 { bf16_t* w; bf16_t* wt; int64_t ldt; };   // bf16 copy [N,K] and transposed copy [K, ldt]
+struct W8 { unsigned char* w; float* scale; };         // fp8 path: e4m3 copy [N,K] quantised per output row, scale [N]
 
 struct EncAct {
     float *x_in, *x_mid, *st1, *st2, *lse;
@@ -84,6 +85,18 @@ struct kzv_model {
     hipGraphExec_t dgraph[2] = {nullptr, nullptr};
     const void* dg_key[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
     int64_t dg_ld[2] = {0, 0};
+    // fp8 weight path (kzv_set_fp8; BASELINE configs[4]): the encoder's QKV, fc1 and fc2 FORWARD GEMMs read e4m3 operands.
+    // Weights: one e4m3 copy per matrix, quantised per output row from the fp32 master at kzv_model_sync_weights.  Activations:
+    // LayerNorm writes an e4m3 copy of its output beside the bf16 one, quantised per token row (x8, x8_scale); the fc1 GELU
+    // epilogue writes an e4m3 copy of the activation with a per-tensor multiplier (f8_q[layer]) derived from the largest |value|
+    // the previous forward saw (f8_amax[layer]; "delayed scaling").  Backward and the output projection stay bf16.
+    int fp8 = 0;
+    std::vector<W8> w8_qkv, w8_fc1, w8_fc2;
+    KzvQuantDesc* d_qdesc = nullptr; int nqdesc = 0, qrows = 0;
+    std::vector<KzvQuantDesc> h_qdesc;
+    unsigned char *x8 = nullptr, *act8 = nullptr;
+    float *x8_scale = nullptr, *f8_q = nullptr, *f8_amax = nullptr, *f8_rows = nullptr;
+    int64_t f8_stride = 0;
     bool side_ok = false;    // mode 2: set only inside the encoder-layer schedule (everything else stays on the caller's stream)
     int side_mode = 0;       // 0 off, 1 free-running wgrads, 2 wgrads only under the HBM-bound kernels (LayerNorm / attention backward)
 };
@@ -167,6 +180,15 @@ W16 take_w(kzv_model* m, Bump& b, int64_t woff, int64_t N, int64_t K, bool need_
     return w;
 }
 
+W8 take_w8(kzv_model* m, Bump& b, int64_t woff, int64_t N, int64_t K) {
+    W8 w;
+    w.w = b.take<unsigned char>(N * K);
+    w.scale = b.take<float>(N);
+    m->h_qdesc.push_back(KzvQuantDesc{m->P ? m->P + woff : nullptr, w.w, w.scale, (int)N, (int)K, m->qrows});
+    m->qrows += (int)N;
+    return w;
+}
+
 int64_t plan(kzv_model* m, char* base, int B, int L) {
     Bump b{base};
     const int T = L - 1;
@@ -199,6 +221,21 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
     m->ndesc = (int)m->h_desc.size();
     m->d_desc = b.take<KzvCastDesc>(m->ndesc);
     const int64_t weights_end = b.off;
+    m->h_qdesc.clear(); m->qrows = 0;
+    if (m->fp8) {
+        m->w8_qkv.resize(m->Le); m->w8_fc1.resize(m->Le); m->w8_fc2.resize(m->Le);
+        for (int i = 0; i < m->Le; ++i) {
+            m->w8_qkv[i] = take_w8(m, b, m->ep[i].qkvw, 3 * He, He);
+            m->w8_fc1[i] = take_w8(m, b, m->ep[i].fc1w, Fe, He);
+            m->w8_fc2[i] = take_w8(m, b, m->ep[i].fc2w, He, Fe);
+        }
+        m->nqdesc = (int)m->h_qdesc.size();
+        m->d_qdesc = b.take<KzvQuantDesc>(m->nqdesc);
+        m->x8 = b.take<unsigned char>(Me * He); m->act8 = b.take<unsigned char>(Me * Fe);
+        m->x8_scale = b.take<float>(Me);
+        m->f8_q = b.take<float>(m->Le); m->f8_amax = b.take<float>(m->Le);
+        m->f8_stride = Me; m->f8_rows = b.take<float>(Me * m->Le);
+    }
 
     // scalars
     m->count = b.take<float>(64); m->loss_acc = m->count + 1; m->err = (int*)(m->count + 2);
@@ -270,6 +307,19 @@ int gemm(const bf16_t* A, int64_t lda, const W16& w, bool transposed, int M, int
     a.C = C; a.ldc = ldc; a.bias = bias; a.resid = resid; a.ldr = ldc; a.aux = aux; a.ldaux = ldaux;
     a.M = M; a.N = N; a.K = K; a.n_valid = n_valid; a.drop_p = drop_p; a.drop_key = drop_key;
     return kzv_gemm_nt(&a, epi, s);
+}
+
+// fp8 forward GEMM of the encoder: A e4m3 with one scale per row, W e4m3 with one scale per output row
+int gemm8(const unsigned char* A, int64_t lda, const float* a_scale, const W8& w, int M, int N, int K, const float* bias, void* C, int64_t ldc,
+          int epi, hipStream_t s, const float* resid = nullptr, void* aux = nullptr, int64_t ldaux = 0, float drop_p = 0.f, uint32_t drop_key = 0,
+          unsigned char* c8 = nullptr, const float* c8_qscale = nullptr, float* c8_amax = nullptr) {
+    kzv_gemm_nt_fp8_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.a_scale = a_scale; a.B = w.w; a.ldb = K; a.b_scale = w.scale;
+    a.C = C; a.ldc = ldc; a.bias = bias; a.resid = resid; a.ldr = ldc; a.aux = aux; a.ldaux = ldaux;
+    a.c8 = c8; a.ldc8 = N; a.c8_qscale = c8_qscale; a.c8_amax = c8_amax;
+    a.M = M; a.N = N; a.K = K; a.n_valid = N; a.drop_p = drop_p; a.drop_key = drop_key;
+    return kzv_gemm_nt_fp8(&a, epi, s);
 }
 
 int wgrad(const bf16_t* dY, int64_t ldp, const bf16_t* X, int64_t ldq, float* dW, int Mtok, int N, int K, int n_store, hipStream_t s,
@@ -360,20 +410,31 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     KZV_TRY(kzv_embed_assemble(m->pe32, P + m->cls, P + m->pos, x0, B, m->npa, He, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_EMB), s,
                                m->img_w / c.patch_w, c.image_w / c.patch_w));
     // ---- ViT layers (pre-LN; HF modeling_vit.py:257-286) -----------------------------------------------
+    const bool f8 = m->fp8 != 0;
+    if (f8) KZV_TRY(kzv_fp8_roll(m->f8_q, m->f8_amax, m->f8_rows, m->Le, (int)m->f8_stride, s));
     for (int i = 0; i < m->Le; ++i) {
         EncAct& a = m->ea[i];
         const EncLayerP& e = m->ep[i];
         float* x_out = i + 1 < m->Le ? m->ea[i + 1].x_in : m->x_last;
-        KZV_TRY(kzv_ln_fwd_ex(a.x_in, P + e.ln1w, P + e.ln1b, a.ln1, nullptr, a.st1, Me, He, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(kzv_ln_fwd_ex(a.x_in, P + e.ln1w, P + e.ln1b, a.ln1, nullptr, a.st1, Me, He, eps, 1, 0, 0.f, 0, s, f8 ? m->x8 : nullptr, f8 ? m->x8_scale : nullptr));
+        if (f8) KZV_TRY(gemm8(m->x8, He, m->x8_scale, m->w8_qkv[i], Me, 3 * He, He, P + e.qkvb, a.qkv, 3 * He, KZV_EPI_BF16, s));
+        else
         KZV_TRY(gemm(a.ln1, He, m->w_eqkv[i], false, Me, 3 * He, He, 3 * He, P + e.qkvb, a.qkv, 3 * He, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, false, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, nullptr, nullptr, nullptr, nullptr,
                      c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, B, He / c.enc_heads));
         KZV_TRY(gemm(a.ctx, He, m->w_eo[i], false, Me, He, He, He, P + e.ob, a.x_mid, He, KZV_EPI_RESID, s, a.x_in, nullptr, 0,
                      dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
-        KZV_TRY(kzv_ln_fwd_ex(a.x_mid, P + e.ln2w, P + e.ln2b, a.ln2, nullptr, a.st2, Me, He, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(kzv_ln_fwd_ex(a.x_mid, P + e.ln2w, P + e.ln2b, a.ln2, nullptr, a.st2, Me, He, eps, 1, 0, 0.f, 0, s, f8 ? m->x8 : nullptr, f8 ? m->x8_scale : nullptr));
+        if (f8) {
+            KZV_TRY(gemm8(m->x8, He, m->x8_scale, m->w8_fc1[i], Me, Fe, He, P + e.fc1b, a.act, Fe, KZV_EPI_GELU, s, nullptr, a.pre, Fe, 0.f, 0,
+                          m->act8, m->f8_q + i, m->f8_amax + i));
+            KZV_TRY(gemm8(m->act8, Fe, m->f8_rows + (int64_t)i * m->f8_stride, m->w8_fc2[i], Me, He, Fe, P + e.fc2b, x_out, He, KZV_EPI_RESID, s,
+                          a.x_mid, nullptr, 0, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 2)));
+        } else {
         KZV_TRY(gemm(a.ln2, He, m->w_efc1[i], false, Me, Fe, He, Fe, P + e.fc1b, a.act, Fe, KZV_EPI_GELU, s, nullptr, a.pre, Fe));
         KZV_TRY(gemm(a.act, Fe, m->w_efc2[i], false, Me, He, Fe, He, P + e.fc2b, x_out, He, KZV_EPI_RESID, s, a.x_mid, nullptr, 0,
                      dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 2)));
+        }
     }
     // final LN, drop CLS (trocr_model.py:197-200), projection (:269)
     KZV_TRY(kzv_ln_fwd_ex(m->x_last, P + m->lnf_w, P + m->lnf_b, m->enc_out, nullptr, m->stf, Me, He, eps, m->Sa, 1, 0.f, 0, s));
@@ -668,6 +729,14 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
     if (hipMemset(d_workspace, 0, wbytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: memset");
     if (hipMemcpy(m->d_desc, m->h_desc.data(), sizeof(KzvCastDesc) * m->ndesc, hipMemcpyHostToDevice) != hipSuccess)
         return kzv_fail(KZV_E_HIP, "model_bind: descriptor upload");
+    if (m->fp8) {
+        if (hipMemcpy(m->d_qdesc, m->h_qdesc.data(), sizeof(KzvQuantDesc) * m->nqdesc, hipMemcpyHostToDevice) != hipSuccess)
+            return kzv_fail(KZV_E_HIP, "model_bind: fp8 descriptor upload");
+        const std::vector<float> ones((size_t)m->Le, 1.f);
+        if (hipMemcpy(m->f8_q, ones.data(), sizeof(float) * m->Le, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(m->f8_amax, 0, sizeof(float) * m->Le) != hipSuccess)
+            return kzv_fail(KZV_E_HIP, "model_bind: fp8 scale state");
+    }
     if (!m->side) {
         const char* e = getenv("KZV_SIDE_STREAM");
         // KZV_SIDE_STREAM: 0 (default) = one stream; 1 = weight gradients free-running on a side stream: +3 % img/s
@@ -691,7 +760,29 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
 
 extern "C" int kzv_model_sync_weights(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "sync_weights: model not bound");
-    return kzv_cast_weights(m->d_desc, m->ndesc, m->cast_tiles, (hipStream_t)stream);
+    KZV_TRY(kzv_cast_weights(m->d_desc, m->ndesc, m->cast_tiles, (hipStream_t)stream));
+    if (m->fp8) KZV_TRY(kzv_quant_rows(m->d_qdesc, m->nqdesc, m->qrows, (hipStream_t)stream));
+    return KZV_OK;
+}
+
+// fp8 weight path on / off; before kzv_model_bind (the workspace layout depends on it).
+extern "C" int kzv_set_fp8(kzv_model* m, int mode) {
+    if (!m) return kzv_fail(KZV_E_ARG, "set_fp8: null model");
+    if (m->bound) return kzv_fail(KZV_E_STATE, "set_fp8: call before kzv_model_bind");
+    if (mode != 0 && mode != 1) return kzv_fail(KZV_E_ARG, "set_fp8: mode 0 (bf16) or 1 (e4m3 forward GEMMs of the encoder)");
+    if (mode && (m->He % 256 || m->Fe % 256))
+        return kzv_fail(KZV_E_ARG, "set_fp8: encoder hidden %d and ffn %d must be multiples of 256 (128-byte K-tiles in pairs)", m->He, m->Fe);
+    m->fp8 = mode;
+    return KZV_OK;
+}
+extern "C" int kzv_get_fp8(const kzv_model* m) { return m ? m->fp8 : 0; }
+
+// parity hook: the per-tensor multipliers the LAST forward quantised each layer's GELU output with -> d_out[enc_layers]
+extern "C" int kzv_fp8_act_scales(const kzv_model* m, float* d_out, void* stream) {
+    if (!m || !m->bound || !m->fp8 || !d_out) return kzv_fail(KZV_E_STATE, "fp8_act_scales: needs a bound model with the fp8 path on");
+    if (hipMemcpyAsync(d_out, m->f8_q, sizeof(float) * m->Le, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return kzv_fail(KZV_E_HIP, "fp8_act_scales: copy");
+    return KZV_OK;
 }
 
 extern "C" int kzv_forward_loss(kzv_model* m, const float* d_pixel_values, const int64_t* d_labels, float* d_loss,

@@ -36,6 +36,16 @@ class kzv_gemm_nt_args(C.Structure):
                 ("drop_p", C.c_float), ("drop_key", C.c_uint32)]
 
 
+class kzv_gemm_nt_fp8_args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64),
+                ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("bias", C.c_void_p),
+                ("resid", C.c_void_p), ("ldr", C.c_int64), ("aux", C.c_void_p), ("ldaux", C.c_int64),
+                ("c8", C.c_void_p), ("ldc8", C.c_int64), ("c8_qscale", C.c_void_p), ("c8_amax", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("n_valid", C.c_int32),
+                ("drop_p", C.c_float), ("drop_key", C.c_uint32)]
+
+
 class kzv_gemm_tn_args(C.Structure):
     _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("Q", C.c_void_p), ("ldq", C.c_int64),
                 ("OUT", C.c_void_p), ("ldo", C.c_int64),
@@ -91,6 +101,12 @@ SYMBOLS = {
     "kzv_lerp_params": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "kzv_gemm_nt": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
     "kzv_set_rows_max_m": (C.c_int, [C.c_int]),
+    "kzv_gemm_nt_fp8": (C.c_int, [C.POINTER(kzv_gemm_nt_fp8_args), C.c_int, _P]),
+    "kzv_quant_rows_fp8": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "kzv_layernorm_fwd_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
+    "kzv_set_fp8": (C.c_int, [_P, C.c_int]),
+    "kzv_get_fp8": (C.c_int, [_P]),
+    "kzv_fp8_act_scales": (C.c_int, [_P, _P, _P]),
     "kzv_gemm_tn": (C.c_int, [C.POINTER(kzv_gemm_tn_args), _P]),
     "kzv_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "kzv_layernorm_bwd": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),

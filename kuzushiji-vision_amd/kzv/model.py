@@ -30,7 +30,8 @@ class TrOCRModel:
 
     def __init__(self, encoder_config: dict[str, Any], decoder_path: str, learning_rate: float = 1e-4,
                  beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8, weight_decay: float = 0,
-                 *, device: str = "cuda", init_seed: int = 42, load_tokenizer: bool = True, width_buckets=None):
+                 *, device: str = "cuda", init_seed: int = 42, load_tokenizer: bool = True, width_buckets=None,
+                 fp8: bool = False):
         import torch
         self.hparams = types.SimpleNamespace(encoder_config=encoder_config, decoder_path=decoder_path,
                                              learning_rate=learning_rate, beta1=beta1, beta2=beta2,
@@ -73,6 +74,11 @@ class TrOCRModel:
         h = C.c_void_p()
         L.check(lib.kzv_model_create(C.byref(self._ccfg), C.byref(h)), "kzv_model_create")
         self._h = h
+        # fp8 weight path (BASELINE.json configs[4]; an extension -- the reference trains in bf16 autocast): the encoder's QKV,
+        # fc1 and fc2 forward GEMMs read e4m3 weights and activations (include/kzv.h: kzv_set_fp8); backward stays bf16.
+        self.fp8 = bool(fp8)
+        if self.fp8:
+            L.check(lib.kzv_set_fp8(h, 1), "kzv_set_fp8")
         self._offsets, total = P.param_offsets(c)
         if lib.kzv_param_total(h) != total:
             raise L.KzvError("parameter table mismatch between kzv/params.py and libkzv")
@@ -106,6 +112,14 @@ class TrOCRModel:
             name = "decoder." + k
             if name in mine and tuple(mine[name].shape) == tuple(v.shape):
                 mine[name].copy_(v.to(self.device, dtype=mine[name].dtype))
+
+    def fp8_act_scales(self):
+        """Per-layer multipliers the last forward quantised the encoder's GELU outputs with (parity hook)."""
+        import torch
+        out = torch.empty(self.cfg.enc_layers, dtype=torch.float32, device=self.device)
+        L.check(L.load().kzv_fp8_act_scales(self._h, out.data_ptr(), L.stream_handle()), "kzv_fp8_act_scales")
+        torch.cuda.synchronize()
+        return out.cpu()
 
     def _bind(self, batch: int, label_len: int) -> None:
         import torch

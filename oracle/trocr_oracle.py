@@ -58,6 +58,53 @@ def _attention(q, k, v, nh, add_mask=None, masks=None, site=None):
     return o.transpose(1, 2).reshape(B, S, -1)
 
 
+# ---- fp8 weight path (BASELINE.json configs[4]; NOT in the reference, which has no fp8: this restates the build's own
+# quantisation recipe -- include/kzv.h "fp8 weight path" -- so that the HIP kernels can be checked against exact arithmetic) ----
+FP8_MAX = 448.0     # largest finite OCP e4m3fn value
+
+
+def quant_e4m3(x):
+    """Nearest OCP e4m3fn value of every element (4 exponent bits, bias 7; 3 mantissa bits; subnormals; round to nearest
+    even; saturating at +-448), returned as float32.  Restated from the format: spacing 2^(e-3) in binade e >= -6, 2^-9 below."""
+    x = x.detach().to(torch.float32)
+    _, e = torch.frexp(x)                                  # x = m * 2^e, m in [0.5, 1)  ->  binade exponent = e - 1
+    step = torch.ldexp(torch.ones_like(x), torch.clamp(e - 1, min=-6) - 3)
+    return torch.clamp(torch.round(x / step) * step, -FP8_MAX, FP8_MAX)    # torch.round = half to even
+
+
+def quant_rows_e4m3(x):
+    """Per-row quantisation (kzv_quant_rows_fp8; LayerNorm's fp8 output): q = e4m3(x * (448 / amax_row)), scale = amax_row / 448
+    (an all-zero row keeps scale 1).  fp32 arithmetic like the kernels.  Returns (q as float32, scale [..., 1])."""
+    x32 = x.detach().to(torch.float32)
+    amax = x32.abs().amax(dim=-1, keepdim=True)
+    nz = amax > 0
+    qs = torch.where(nz, torch.tensor(FP8_MAX, dtype=torch.float32) / amax, torch.ones_like(amax))
+    scale = torch.where(nz, amax / torch.tensor(FP8_MAX, dtype=torch.float32), torch.ones_like(amax))
+    return quant_e4m3(x32 * qs), scale
+
+
+def next_act_qscale(amax: float, prev: float = 1.0) -> float:
+    """Delayed scaling of the per-tensor sites (kzv_fp8_roll): a power of two with one binade of headroom below 448 / amax;
+    unchanged while nothing has been seen."""
+    return prev if amax <= 0 else 2.0 ** (math.floor(math.log2(FP8_MAX / amax)) - 1)
+
+
+def _linear_fp8(h, W, b, act_qscale=None):
+    """F.linear on e4m3 operands: W quantised per output row; h per token row, or per tensor with multiplier ``act_qscale``.
+    Forward value = (hq Wq^T) * scales + b in h's dtype; gradients are those of the unquantised linear (the build's backward
+    reads the bf16 operands: straight-through)."""
+    wq, ws = quant_rows_e4m3(W)
+    if act_qscale is None:
+        hq, hs = quant_rows_e4m3(h)
+    else:
+        hq = quant_e4m3(h.detach().to(torch.float32) * float(act_qscale))
+        hs = torch.full(h.shape[:-1] + (1,), 1.0 / float(act_qscale), dtype=torch.float32)
+    dt = h.dtype
+    val = torch.matmul(hq.to(dt), wq.to(dt).t()) * hs.to(dt) * ws.to(dt).reshape(1, -1) + b.detach()
+    plain = F.linear(h, W, b)
+    return plain + (val - plain).detach()
+
+
 def patch_embed(cfg, sd, pixel_values):
     """CustomPatchEmbeddings.forward -- src/models/trocr_model.py:79-92 (Conv2d k=s=patch; h-major patches)."""
     B, C, H, W = pixel_values.shape
@@ -68,10 +115,12 @@ def patch_embed(cfg, sd, pixel_values):
     return x.flatten(2).transpose(1, 2)
 
 
-def encoder_forward(cfg, sd, pixel_values, stages=None, masks=None):
+def encoder_forward(cfg, sd, pixel_values, stages=None, masks=None, fp8=None):
     """ViTEncoder.forward -- src/models/trocr_model.py:169-202; layers = HF ViTLayer (modeling_vit.py:257-286).
     Dropout sites (training): embeddings :190 ("enc_emb"), attention probabilities ("enc{i}_attn"), ViTLayer.dropout after
-    the attention block (modeling_vit.py:276, "enc{i}_o") and after the MLP (:283, "enc{i}_mlp")."""
+    the attention block (modeling_vit.py:276, "enc{i}_o") and after the MLP (:283, "enc{i}_mlp").
+    ``fp8`` (the build's fp8 weight path, not the reference): {"act_qscale": [per-layer multiplier of the GELU output]} runs
+    query/key/value, intermediate.dense and output.dense through _linear_fp8; stages["enc{i}_act_amax"] records max |GELU|."""
     B = pixel_values.shape[0]
     x = patch_embed(cfg, sd, pixel_values)
     if stages is not None:
@@ -84,14 +133,21 @@ def encoder_forward(cfg, sd, pixel_values, stages=None, masks=None):
     for i in range(cfg.enc_layers):
         p = f"encoder.encoder.layer.{i}."
         h = _ln(x, sd[p + "layernorm_before.weight"], sd[p + "layernorm_before.bias"], cfg.ln_eps)
-        q = F.linear(h, sd[p + "attention.attention.query.weight"], sd[p + "attention.attention.query.bias"])
-        k = F.linear(h, sd[p + "attention.attention.key.weight"], sd[p + "attention.attention.key.bias"])
-        v = F.linear(h, sd[p + "attention.attention.value.weight"], sd[p + "attention.attention.value.bias"])
+        lin = F.linear if fp8 is None else _linear_fp8
+        q = lin(h, sd[p + "attention.attention.query.weight"], sd[p + "attention.attention.query.bias"])
+        k = lin(h, sd[p + "attention.attention.key.weight"], sd[p + "attention.attention.key.bias"])
+        v = lin(h, sd[p + "attention.attention.value.weight"], sd[p + "attention.attention.value.bias"])
         a = _attention(q, k, v, nh, None, masks, f"enc{i}_attn")
         x = x + _drop(F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"]), masks, f"enc{i}_o")
         h = _ln(x, sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"], cfg.ln_eps)
-        h = _gelu(F.linear(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
-        x = x + _drop(F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"]), masks, f"enc{i}_mlp")
+        h = _gelu(lin(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        if fp8 is None:
+            y = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        else:
+            if stages is not None:
+                stages[f"enc{i}_act_amax"] = h.detach().abs().max()
+            y = _linear_fp8(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"], fp8["act_qscale"][i])
+        x = x + _drop(y, masks, f"enc{i}_mlp")
         if stages is not None:
             stages[f"enc_layer{i}"] = x
     x = _ln(x, sd["encoder.layernorm.weight"], sd["encoder.layernorm.bias"], cfg.ln_eps)  # :197
@@ -157,10 +213,10 @@ def decoder_forward(cfg, sd, input_ids, enc, stages=None, masks=None):
     return F.linear(h, sd[r + "embeddings.word_embeddings.weight"], sd["decoder.lm_head.bias"])
 
 
-def forward(cfg, sd, pixel_values, labels, stages=None, masks=None):
+def forward(cfg, sd, pixel_values, labels, stages=None, masks=None, fp8=None):
     """TrOCRModel.forward, training branch -- src/models/trocr_model.py:258-297.  Returns (logits, loss).
     ``masks`` (optional): explicit dropout multipliers per site, see _drop; None = eval mode."""
-    enc = encoder_forward(cfg, sd, pixel_values, stages, masks)
+    enc = encoder_forward(cfg, sd, pixel_values, stages, masks, fp8)
     if cfg.has_proj:
         enc = F.linear(enc, sd["encoder_decoder_proj.weight"], sd["encoder_decoder_proj.bias"])  # :269
     if stages is not None:
@@ -184,13 +240,13 @@ def leaf_state_dict(sd_np, dtype=torch.float32, requires_grad=True):
     return out
 
 
-def forward_backward(cfg, sd_np, pixel_values, labels, dtype=torch.float32, want_stages=False, masks=None):
+def forward_backward(cfg, sd_np, pixel_values, labels, dtype=torch.float32, want_stages=False, masks=None, fp8=None):
     """One teacher-forced step; returns dict(logits, loss, grads{hf_name: ndarray}, stages)."""
     sd = leaf_state_dict(sd_np, dtype)
     stages = {} if want_stages else None
     if masks is not None:
         masks = {k: torch.as_tensor(v) for k, v in masks.items()}
-    logits, loss = forward(cfg, sd, torch.as_tensor(pixel_values).to(dtype), torch.as_tensor(labels), stages, masks)
+    logits, loss = forward(cfg, sd, torch.as_tensor(pixel_values).to(dtype), torch.as_tensor(labels), stages, masks, fp8)
     loss.backward()
     grads = {k: (v.grad.detach().numpy() if v.grad is not None else None) for k, v in sd.items()}
     return {"logits": logits.detach().numpy(), "loss": float(loss.detach()), "grads": grads,

@@ -1,0 +1,239 @@
+"""fp8 weight path (BASELINE.json configs[4], second half; include/kzv.h "fp8 weight path").  The reference has no fp8, so the
+checks are against the oracle restating the SAME quantisation recipe in exact arithmetic
+(oracle/trocr_oracle.py: quant_e4m3 / quant_rows_e4m3 / _linear_fp8) and against the build's own bf16 path:
+
+  * the quantiser kernels bit-for-bit (e4m3 bytes and scales) against the oracle's restatement;
+  * kzv_gemm_nt_fp8 (block-scaled MFMA, every epilogue, edge tiles, dropout, the e4m3 copy of a GELU output and its amax)
+    against fp64 products of the decoded operands;
+  * a whole training step with the fp8 switch on: logits, loss and every gradient against the fake-quantising oracle, the
+    delayed per-tensor multipliers against the oracle's amax, and the distance to the bf16 path of the same weights.
+"""
+import ctypes as C
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from kzv import _lib as L
+from kzv import params as P
+from kzv.config import ModelConfig
+from kzv.data import build_decoder_dir, synthetic_batch
+from kzv.model import TrOCRModel
+from oracle import trocr_oracle as O
+
+from _replay import step_masks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.load()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _decode(q8: torch.Tensor) -> torch.Tensor:
+    """e4m3 bytes -> float32 (torch's own float8_e4m3fn view: an implementation independent of kernel and oracle)."""
+    return q8.cpu().view(torch.float8_e4m3fn).float()
+
+
+def _quant_rows(lib, x):
+    rows, cols = x.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    L.check(lib.kzv_quant_rows_fp8(x.data_ptr(), rows, cols, q.data_ptr(), sc.data_ptr(), _st()), "quant_rows_fp8")
+    return q, sc
+
+
+# ------------------------------------------------------------------------------------------------ quantisers
+@pytest.mark.parametrize("rows,cols", [(1, 4), (7, 64), (300, 768), (64, 3072), (5, 260)])
+def test_quant_rows_bit_exact(lib, rows, cols):
+    torch.manual_seed(rows * cols)
+    x = torch.randn(rows, cols, device=DEV) * torch.logspace(-6, 4, rows, device=DEV).unsqueeze(1)
+    if rows > 2:
+        x[1].zero_()                         # all-zero row: scale 1, bytes 0
+        x[2, 0] = 3.0e30                     # one huge outlier: everything else underflows to (sub)normals / 0
+    q, sc = _quant_rows(lib, x)
+    torch.cuda.synchronize()
+    q_ref, sc_ref = O.quant_rows_e4m3(x.cpu())
+    assert torch.equal(sc.cpu(), sc_ref.reshape(-1))
+    assert torch.equal(_decode(q), q_ref)
+
+
+@pytest.mark.parametrize("rows,H", [(50, 256), (161, 768), (9, 1024)])
+def test_layernorm_fp8_copy(lib, rows, H):
+    torch.manual_seed(H)
+    x = torch.randn(rows, H, device=DEV) * 3 + 0.5
+    g = torch.randn(H, device=DEV)
+    b = torch.randn(H, device=DEV)
+    y16 = torch.empty(rows, H, dtype=torch.bfloat16, device=DEV)
+    y8 = torch.empty(rows, H, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    st = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
+    L.check(lib.kzv_layernorm_fwd_fp8(x.data_ptr(), g.data_ptr(), b.data_ptr(), y16.data_ptr(), y8.data_ptr(), sc.data_ptr(),
+                                      st.data_ptr(), rows, H, 1e-12, _st()), "ln_fp8")
+    y16b = torch.empty_like(y16)
+    L.check(lib.kzv_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y16b.data_ptr(), None, None, rows, H, 1e-12, _st()), "ln")
+    torch.cuda.synchronize()
+    assert torch.equal(y16, y16b)                                     # the bf16 output is the plain kernel's
+    ref = torch.nn.functional.layer_norm(x.double(), (H,), g.double(), b.double(), 1e-12).cpu()
+    amax = ref.abs().amax(dim=1)
+    assert torch.allclose(sc.cpu().double() * 448.0, amax, rtol=1e-5)
+    deq = _decode(y8).double() * sc.cpu().double().unsqueeze(1)
+    # e4m3: half a unit in the last place is 2^-4 relative (normals), 2^-10 of the scaled range below 2^-6
+    tol = ref.abs() * 2.0 ** -4 * 1.001 + (sc.cpu().double() * 2.0 ** -10).unsqueeze(1) + 1e-5 * amax.unsqueeze(1)
+    assert bool(((deq - ref).abs() <= tol).all())
+
+
+# ------------------------------------------------------------------------------------------------ the GEMM
+def _gemm8(lib, A8, sa, B8, sb, epi, M, N, K, bias=None, resid=None, aux=None, drop_p=0.0, key=0, c8=None, c8_q=None, c8_amax=None):
+    out = torch.empty(M, N, dtype=torch.float32 if epi == L.EPI_RESID else torch.bfloat16, device=DEV)
+    a = L.kzv_gemm_nt_fp8_args(A=A8.data_ptr(), lda=K, B=B8.data_ptr(), ldb=K, a_scale=sa.data_ptr(), b_scale=sb.data_ptr(),
+                               C=out.data_ptr(), ldc=N, bias=L.ptr(bias), resid=L.ptr(resid), ldr=N, aux=L.ptr(aux), ldaux=N,
+                               c8=L.ptr(c8), ldc8=N, c8_qscale=L.ptr(c8_q), c8_amax=L.ptr(c8_amax), M=M, N=N, K=K, n_valid=N,
+                               drop_p=drop_p, drop_key=key)
+    L.check(lib.kzv_gemm_nt_fp8(C.byref(a), epi, _st()), "gemm_nt_fp8")
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (700, 768, 768), (1288, 2304, 768), (515, 768, 3072), (100, 260, 512), (4121, 1024, 1024)])
+def test_gemm_nt_fp8_epilogues(lib, M, N, K):
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV) * (1 + 5 * torch.rand(M, 1, device=DEV))
+    B = torch.randn(N, K, device=DEV) * 0.05 * (1 + 3 * torch.rand(N, 1, device=DEV))
+    bias = torch.randn(N, device=DEV)
+    A8, sa = _quant_rows(lib, A)
+    B8, sb = _quant_rows(lib, B)
+    torch.cuda.synchronize()
+    ref = ((_decode(A8).double() @ _decode(B8).double().t()) * sa.cpu().double().unsqueeze(1) * sb.cpu().double().unsqueeze(0)
+           + bias.cpu().double())
+    scale = ref.abs().max().item()
+    # the quantised product stays close to the unquantised one (3-bit mantissas on both sides, K random terms)
+    exact = A.cpu().double() @ B.cpu().double().t() + bias.cpu().double()
+    assert (ref - exact).abs().max().item() < 0.08 * scale
+
+    resid = torch.randn(M, N, device=DEV)
+    got = _gemm8(lib, A8, sa, B8, sb, L.EPI_RESID, M, N, K, bias, resid=resid)
+    assert (got.cpu().double() - (ref + resid.cpu().double())).abs().max().item() < 3e-5 * scale + 1e-5     # fp32 accumulate
+    got = _gemm8(lib, A8, sa, B8, sb, L.EPI_BF16, M, N, K, bias)
+    assert (got.cpu().double() - ref).abs().max().item() < 2 ** -8 * scale
+    # GELU: activation, saved derivative, e4m3 copy with a per-tensor multiplier, running amax
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    c8 = torch.empty(M, N, dtype=torch.uint8, device=DEV)
+    qs = torch.tensor([4.0], device=DEV)
+    amax = torch.zeros(1, device=DEV)
+    got = _gemm8(lib, A8, sa, B8, sb, L.EPI_GELU, M, N, K, bias, aux=aux, c8=c8, c8_q=qs, c8_amax=amax)
+    torch.cuda.synchronize()
+    y = torch.nn.functional.gelu(ref)
+    assert (got.cpu().double() - y).abs().max().item() < 2 ** -8 * scale
+    dref = 0.5 * (1 + torch.erf(ref / 2 ** 0.5)) + ref * torch.exp(-0.5 * ref * ref) / (2 * math.pi) ** 0.5
+    assert (aux.cpu().double() - dref).abs().max().item() < 2 ** -8 * 1.2 + 1e-3
+    assert abs(amax.item() - y.abs().max().item()) < 1e-4 * scale
+    y8 = _decode(c8).double() / 4.0
+    yc = torch.clamp(y, -112.0, 112.0)                                   # 448 / 4: saturates, never NaN
+    assert bool(((y8 - yc).abs() <= yc.abs() * 2.0 ** -4 * 1.01 + 2.0 ** -10 / 4.0 + 1e-4 * scale).all())
+    # dropout: the kernel's own mask, element index m * N + n (kzv_debug_dropout_mask)
+    key = lib.kzv_drop_key(1234, 18)
+    got = _gemm8(lib, A8, sa, B8, sb, L.EPI_RESID, M, N, K, bias, resid=resid, drop_p=0.1, key=key)
+    mask = torch.empty(M, N, device=DEV)
+    L.check(lib.kzv_debug_dropout_mask(key, 0.1, M, N, N, mask.data_ptr(), _st()), "mask")
+    torch.cuda.synchronize()
+    assert (got.cpu().double() - (ref * mask.cpu().double() + resid.cpu().double())).abs().max().item() < 4e-5 * scale + 1e-5
+
+
+def test_gemm_nt_fp8_rejects_unsupported_arguments(lib):
+    A8 = torch.zeros(256, 320, dtype=torch.uint8, device=DEV)
+    s = torch.ones(256, device=DEV)
+    out = torch.empty(256, 256, dtype=torch.bfloat16, device=DEV)
+    a = L.kzv_gemm_nt_fp8_args(A=A8.data_ptr(), lda=320, B=A8.data_ptr(), ldb=320, a_scale=s.data_ptr(), b_scale=s.data_ptr(),
+                               C=out.data_ptr(), ldc=256, M=256, N=256, K=320, n_valid=256)
+    assert lib.kzv_gemm_nt_fp8(C.byref(a), L.EPI_BF16, _st()) != 0          # K must be a multiple of 256
+    a.K = 256
+    assert lib.kzv_gemm_nt_fp8(C.byref(a), L.EPI_DGELU, _st()) != 0         # backward epilogues stay bf16
+    a.a_scale = None
+    assert lib.kzv_gemm_nt_fp8(C.byref(a), L.EPI_BF16, _st()) != 0
+
+
+# ------------------------------------------------------------------------------------------------ the model
+def _f8_config(**kw):
+    """Smallest geometry the fp8 switch accepts (hidden and ffn multiples of 256), head_dim 64, 2 + 2 layers."""
+    base = dict(image_h=32, image_w=128, enc_hidden=256, enc_layers=2, enc_heads=4, enc_ffn=512,
+                dec_hidden=64, dec_layers=2, dec_heads=1, dec_ffn=128, vocab=157, max_pos=40)
+    base.update(kw)
+    return ModelConfig(**base)
+
+
+def _make(cfg, tmp_path, seed=42, **kw):
+    d = build_decoder_dir(str(tmp_path / f"dec{cfg.vocab}_{cfg.enc_hidden}"), cfg)
+    return TrOCRModel(cfg.encoder_config_dict(), d, init_seed=seed, load_tokenizer=False, **kw)
+
+
+def _no_dropout(cfg):
+    return dataclasses.replace(cfg, enc_hidden_dropout=0.0, enc_attn_dropout=0.0, dec_hidden_dropout=0.0, dec_attn_dropout=0.0)
+
+
+def test_fp8_switch_validates_geometry(tmp_path):
+    from kzv.config import tiny_config
+    with pytest.raises(L.KzvError):
+        _make(tiny_config(), tmp_path, fp8=True)                      # hidden 128: not a multiple of 256
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_fp8_step_matches_fake_quant_oracle(tmp_path, dropout):
+    cfg = _f8_config() if dropout else _no_dropout(_f8_config())
+    B, Lh = 6, 24
+    m = _make(cfg, tmp_path, 5, fp8=True)
+    m.trim_padding = False
+    px, lab = synthetic_batch(cfg, B, Lh, seed=9, min_chars=4, max_chars=20)
+    m.train()                               # dropout off = probabilities 0 in the config, still a training step
+    sd = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 5))
+    scales = [1.0] * cfg.enc_layers
+    for step in range(2):        # step 0: multipliers 1 (nothing seen yet); step 1: derived from step 0's amax
+        m.zero_grad()
+        seed = 77 + step
+        loss, logits = m.forward_loss(torch.from_numpy(px), torch.from_numpy(lab), want_logits=True, seed=seed)
+        m.backward()
+        torch.cuda.synchronize()
+        used = m.fp8_act_scales().tolist()
+        assert used == pytest.approx(scales), f"step {step}: delayed multipliers"
+        masks = step_masks(cfg, seed, B, Lh - 1) if dropout else None
+        r = O.forward_backward(cfg, sd, px, lab, want_stages=True, masks=masks, fp8={"act_qscale": used})
+        logits = logits.cpu().numpy()
+        span = np.abs(r["logits"]).max()
+        assert np.abs(logits - r["logits"]).max() < 1.5e-2 * span, f"step {step}"
+        assert abs(float(loss) - r["loss"]) < 5e-3
+        g = m.grad_dict()
+        for k, v in r["grads"].items():
+            if v is None or k.endswith("key.bias"):
+                continue
+            got = g[k].cpu().numpy().reshape(v.shape)
+            assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, (step, k)
+        scales = [O.next_act_qscale(float(r["stages"][f"enc{i}_act_amax"]), scales[i]) for i in range(cfg.enc_layers)]
+        assert all(s > 1.0 for s in scales)                           # GELU outputs here are O(1): the range gets used
+
+
+def test_fp8_path_stays_close_to_the_bf16_path(tmp_path):
+    cfg = _no_dropout(_f8_config(enc_layers=4))
+    B, Lh = 8, 24
+    px, lab = synthetic_batch(cfg, B, Lh, seed=3, min_chars=4, max_chars=20)
+    outs = {}
+    for f8 in (False, True):
+        m = _make(cfg, tmp_path, 11, fp8=f8)
+        m.trim_padding = False
+        m.eval()
+        for _ in range(2):                     # second pass: the delayed multipliers are in use
+            loss, logits = m.forward_loss(torch.from_numpy(px), torch.from_numpy(lab), want_logits=True)
+        torch.cuda.synchronize()
+        outs[f8] = (logits.float().cpu().numpy(), float(loss))
+    a, b = outs[False][0], outs[True][0]
+    span = np.abs(a).max()
+    assert np.abs(a - b).max() < 0.1 * span                          # 3-bit mantissas in three GEMMs of each of 4 layers
+    assert np.sqrt(np.mean((a - b) ** 2)) < 0.02 * span
+    assert abs(outs[False][1] - outs[True][1]) < 0.02 * abs(outs[False][1])
+    assert (a.argmax(-1) == b.argmax(-1)).mean() > 0.9

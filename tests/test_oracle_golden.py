@@ -153,3 +153,20 @@ def test_oracle_explicit_dropout_masks():
         mk = (torch.rand(shp, generator=gen) >= 0.5).float() * 2.0
         out, _ = O.forward(cfg, sd, torch.from_numpy(px), torch.from_numpy(lab), masks={name: mk})
         assert float((out - base).abs().max()) > 1e-6, name      # every site is wired
+
+
+def test_fp8_quantiser_restatement_matches_an_independent_cast():
+    """oracle quant_e4m3 (the fp8 weight path's reference arithmetic, restated from the OCP e4m3fn format) against torch's own
+    float8_e4m3fn conversion on 200k values over 10 decades plus the format's corner cases."""
+    import torch
+    torch.manual_seed(0)
+    x = torch.randn(200000) * 10 ** torch.empty(200000).uniform_(-5, 3)
+    corners = torch.tensor([0.0, -0.0, 448.0, 447.9, 464.0, 500.0, -1e9, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9,
+                            2.0 ** -6, 0.0156, 0.9375, 1.0625, 15.5, 17.0, 240.0, 416.0, 432.0])
+    x = torch.cat([x, corners, -corners])
+    want = torch.clamp(x, -448.0, 448.0).to(torch.float8_e4m3fn).float()
+    assert torch.equal(O.quant_e4m3(x), want)
+    q, s = O.quant_rows_e4m3(torch.tensor([[0.0, 0.0, 0.0, 0.0], [1.0, -2.0, 0.5, 448.0], [3.0, 1.0, -7.0, 0.1]]))
+    assert s.reshape(-1).tolist() == [1.0, 1.0, 7.0 / 448.0]
+    assert q[0].abs().max() == 0 and q[2].abs().max() == 448.0
+    assert O.next_act_qscale(0.0, 8.0) == 8.0 and O.next_act_qscale(3.0) == 64.0 and O.next_act_qscale(448.0) == 0.5
