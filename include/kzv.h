@@ -116,11 +116,34 @@ int kzv_encode_images(kzv_model* m, const float* d_pixel_values, int n_images, v
  * (this step's are appended) and the cross-attention K/V of the last kzv_forward_loss; d_valid [B, ld_valid] marks the
  * usable self-attention keys (key j usable iff token j is not padding; column t must already be set).  Writes logits
  * [B, V] for the next token.  Steps must be issued in order t = 0, 1, ...; the cache is sized [B, L-1] at the first call.
- * kzv_decode_reorder re-orders the cached rows after a beam step: row b continues from former row d_rows[b] (first `len`
- * key positions). */
+ * kzv_decode_reorder re-parents the sequences after a beam step: row b continues from former row d_rows[b] (first `len` key
+ * positions).  No cache row moves: a row table tells the next steps' attention which ancestor's row holds each cached key. */
 int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, int t, const uint8_t* d_valid, int64_t ld_valid,
                     float* d_logits, void* stream);
 int kzv_decode_reorder(kzv_model* m, const int64_t* d_rows, int len, void* stream);
+/* One beam-search step's ranking on the device (what transformers' GenerationMixin._get_top_k_continuations computes with
+ * log_softmax + topk): for each of `batch` images, log_softmax of each of its `num_beams` (<= 8) rows of d_logits [batch *
+ * num_beams, ld] + that beam's d_beam_scores entry, then the k (<= 16) best of the num_beams * vocab continuations, best first;
+ * equal scores rank by the smaller flat index.  d_top_scores [batch, k] fp32, d_top_index [batch, k] int64 = beam * vocab + token. */
+int kzv_beam_topk(const float* d_logits, int64_t ld, const float* d_beam_scores, int batch, int num_beams, int vocab, int k,
+                  float* d_top_scores, int64_t* d_top_index, void* stream);
+/* One beam-search step's bookkeeping on the device -- what transformers' GenerationMixin._beam_search does between two decoder
+ * steps (running beams of the next step, finished list, early-stop heuristic; kzv/beam.py states it in torch ops and is pinned
+ * against HF on the CPU).  State arrays live in caller memory for the whole generation; token rows are double-buffered (the
+ * caller swaps run_seq_in/out and fin_seq_in/out after every call).  `cur` = index of the token being chosen (1 = first after
+ * BOS).  Outputs: d_rows [batch * num_beams] = the former flat row every running beam continues from (for kzv_decode_reorder),
+ * d_flags [3] = {images whose open beams may still improve, images whose finished list is not full, images with a continuation
+ * that did not stop}: the loop goes on iff flags[0] > 0 && !(early_stopping && flags[1] == 0) && flags[2] > 0. */
+typedef struct kzv_beam_state {
+    int32_t batch, num_beams, max_len, vocab, eos_id;
+    const int64_t* run_seq_in; int64_t* run_seq_out;     /* [batch, num_beams, max_len] */
+    const int64_t* fin_seq_in; int64_t* fin_seq_out;     /* [batch, num_beams, max_len] */
+    float* run_scores; float* fin_scores;                /* [batch, num_beams] */
+    uint8_t* fin_done; int64_t* fin_len;                 /* [batch, num_beams] */
+    uint8_t* unsatisfied;                                /* [batch] */
+} kzv_beam_state;
+int kzv_beam_update(const kzv_beam_state* st, const float* d_top_scores, const int64_t* d_top_index, int cur, int early_stopping,
+                    float length_penalty, int64_t* d_rows, int32_t* d_flags, void* stream);
 /* The same step replayed from a hipGraph (the eager step is ~100 small launches and host-bound at ~0.85 ms per token):
  * the step index lives in device memory -- kzv_decode_begin resets it to 0, every kzv_decode_step_graph runs step t and
  * leaves t + 1 -- so one instantiated graph serves every step of a generation.  The graph is captured on the first call

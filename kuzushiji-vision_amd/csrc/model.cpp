@@ -80,11 +80,13 @@ struct kzv_model {
     bool pending[4] = {false, false, false, false}; bool use_side = false, join_each_segment = true;
     // KV cache of the generation path (kzv_decode_step): two copies [2*Ld][B][T][Hd] (beam re-ordering gathers from one into the other)
     bf16_t* kvc[2] = {nullptr, nullptr}; int kv_cur = 0, kvB = 0, kvT = 0;
+    // beam re-parenting by indirection: rowtab[x][b][j] = cache row holding key j of sequence b; rt_cur = -1: identity (no table)
+    int* rowtab[2] = {nullptr, nullptr}; int rt_cur = -1;
     // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
     int* d_t = nullptr;
-    hipGraphExec_t dgraph[2] = {nullptr, nullptr};
-    const void* dg_key[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
-    int64_t dg_ld[2] = {0, 0};
+    hipGraphExec_t dgraph[3] = {nullptr, nullptr, nullptr};          // one per row table in use: none, rowtab[0], rowtab[1]
+    const void* dg_key[3][6] = {};
+    int64_t dg_ld[3] = {0, 0, 0};
     // fp8 weight path (kzv_set_fp8; BASELINE configs[4]): the encoder's QKV, fc1 and fc2 FORWARD GEMMs read e4m3 operands.
     // Weights: one e4m3 copy per matrix, quantised per output row from the fp32 master at kzv_model_sync_weights.  Activations:
     // LayerNorm writes an e4m3 copy of its output beside the bf16 one, quantised per token row (x8, x8_scale); the fc1 GELU
@@ -680,7 +682,8 @@ extern "C" int kzv_model_destroy(kzv_model* m) {
         if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
         for (int i = 0; i < 4; ++i) if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
         for (int i = 0; i < 2; ++i) if (m->kvc[i]) (void)hipFree(m->kvc[i]);
-        for (int i = 0; i < 2; ++i) if (m->dgraph[i]) (void)hipGraphExecDestroy(m->dgraph[i]);
+        for (int i = 0; i < 2; ++i) if (m->rowtab[i]) (void)hipFree(m->rowtab[i]);
+        for (int i = 0; i < 3; ++i) if (m->dgraph[i]) (void)hipGraphExecDestroy(m->dgraph[i]);
     }
     delete m;
     return KZV_OK;
@@ -846,11 +849,14 @@ extern "C" int kzv_decode_logits(kzv_model* m, const int64_t* d_labels, int pos,
 static int ensure_kv_cache(kzv_model* m) {
     if (m->kvc[0] && m->kvB == m->B && m->kvT == m->T) return KZV_OK;
     for (int i = 0; i < 2; ++i) { if (m->kvc[i]) (void)hipFree(m->kvc[i]); m->kvc[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) { if (m->rowtab[i]) (void)hipFree(m->rowtab[i]); m->rowtab[i] = nullptr; }
+    // ONE cache [2*Ld][B][T][Hd]: beam steps re-parent rows through the row tables instead of copying into a second cache
     const size_t bytes = (size_t)2 * m->Ld * m->B * m->T * m->Hd * sizeof(bf16_t);
+    if (hipMalloc((void**)&m->kvc[0], bytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step: KV cache allocation (%zu bytes)", bytes);
     for (int i = 0; i < 2; ++i)
-        if (hipMalloc((void**)&m->kvc[i], bytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step: KV cache allocation (%zu bytes)", bytes);
-    m->kvB = m->B; m->kvT = m->T; m->kv_cur = 0;
-    for (int i = 0; i < 2; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
+        if (hipMalloc((void**)&m->rowtab[i], (size_t)m->B * m->T * sizeof(int)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_step: row table allocation");
+    m->kvB = m->B; m->kvT = m->T; m->kv_cur = 0; m->rt_cur = -1;
+    for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
     return KZV_OK;
 }
 
@@ -875,7 +881,8 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
         const DecLayerP& d = m->dp[i];
         KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, B, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
         KZV_TRY(kzv_attn_decode(a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, cache + (int64_t)(2 * i) * plane, cache + (int64_t)(2 * i + 1) * plane,
-                                (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr));
+                                (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr, 1,
+                                m->rt_cur >= 0 ? m->rowtab[m->rt_cur] : nullptr, T));
         KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, B, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0, 0.f, 0));
         KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, B, Hd, eps, 1, 0, 0.f, 0, s));
         KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
@@ -908,6 +915,7 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
     KZV_TRY(decode_step_check(m, d_tokens, d_posids, d_valid, d_logits, "decode_step"));
     if (t < 0 || t >= m->T) return kzv_fail(KZV_E_ARG, "decode_step: step outside 0..T-1");
     KZV_TRY(ensure_kv_cache(m));
+    if (t == 0) m->rt_cur = -1;                 // a new generation: no beam has been re-parented yet
     m->train = false; m->have_fwd = false;      // decoder activations are overwritten: no backward after this
     return decode_step_body(m, d_tokens, d_posids, t, nullptr, d_valid, ld_valid, d_logits, (hipStream_t)stream);
 }
@@ -915,6 +923,7 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
 extern "C" int kzv_decode_begin(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_begin: model not bound");
     KZV_TRY(ensure_kv_cache(m));
+    m->rt_cur = -1;                              // a new generation: every sequence reads its own cache row
     if (hipMemsetAsync(m->d_t, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_begin: memset");
     return KZV_OK;
 }
@@ -926,8 +935,8 @@ extern "C" int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, cons
     KZV_TRY(ensure_kv_cache(m));
     m->train = false; m->have_fwd = false;
     hipStream_t s = (hipStream_t)stream;
-    const int g = m->kv_cur;
-    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[g], (const void*)(intptr_t)(m->npa * 4096 + m->Be)};
+    const int g = m->rt_cur + 1;
+    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[0], (const void*)(intptr_t)(m->npa * 4096 + m->Be)};
     bool same = m->dgraph[g] != nullptr && m->dg_ld[g] == ld_valid;
     for (int i = 0; i < 6 && same; ++i) same = m->dg_key[g][i] == key[i];
     if (!same) {                               // (re)capture: the step with its index read from m->d_t, then t += 1
@@ -952,8 +961,10 @@ extern "C" int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, cons
 extern "C" int kzv_decode_reorder(kzv_model* m, const int64_t* d_rows, int len, void* stream) {
     if (!m || !m->bound || !m->kvc[0]) return kzv_fail(KZV_E_STATE, "decode_reorder: no KV cache (call kzv_decode_step first)");
     if (!d_rows || len < 1 || len > m->T) return kzv_fail(KZV_E_ARG, "decode_reorder: rows / length");
-    KZV_TRY(kzv_kv_reorder(m->kvc[m->kv_cur], m->kvc[m->kv_cur ^ 1], d_rows, 2 * m->Ld, m->B, m->T, len, m->Hd, (hipStream_t)stream));
-    m->kv_cur ^= 1;
+    // no cache row moves: the next step's attention reads key j of sequence b from the row of the ancestor that wrote it
+    const int nxt = m->rt_cur < 0 ? 0 : m->rt_cur ^ 1;
+    KZV_TRY(kzv_kv_rows(m->rt_cur < 0 ? nullptr : m->rowtab[m->rt_cur], m->rowtab[nxt], d_rows, m->B, m->T, len, (hipStream_t)stream));
+    m->rt_cur = nxt;
     return KZV_OK;
 }
 

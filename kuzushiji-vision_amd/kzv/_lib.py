@@ -46,6 +46,13 @@ class kzv_gemm_nt_fp8_args(C.Structure):
                 ("drop_p", C.c_float), ("drop_key", C.c_uint32)]
 
 
+class kzv_beam_state(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("num_beams", C.c_int32), ("max_len", C.c_int32), ("vocab", C.c_int32), ("eos_id", C.c_int32),
+                ("run_seq_in", C.c_void_p), ("run_seq_out", C.c_void_p), ("fin_seq_in", C.c_void_p), ("fin_seq_out", C.c_void_p),
+                ("run_scores", C.c_void_p), ("fin_scores", C.c_void_p), ("fin_done", C.c_void_p), ("fin_len", C.c_void_p),
+                ("unsatisfied", C.c_void_p)]
+
+
 class kzv_gemm_tn_args(C.Structure):
     _fields_ = [("P", C.c_void_p), ("ldp", C.c_int64), ("Q", C.c_void_p), ("ldq", C.c_int64),
                 ("OUT", C.c_void_p), ("ldo", C.c_int64),
@@ -123,6 +130,8 @@ SYMBOLS = {
     "kzv_decode_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kzv_decode_step_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kzv_decode_reorder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "kzv_beam_update": (C.c_int, [C.POINTER(kzv_beam_state), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kzv_beam_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kzv_lanczos_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "kzv_preprocess_lines": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -48,8 +48,14 @@ def greedy(step, batch: int, max_len: int, pad_id: int, bos_id: int, eos_id: int
 
 
 def beam_search(step, reorder, batch: int, num_beams: int, max_len: int, vocab: int, pad_id: int, bos_id: int, eos_id: int,
-                device, early_stopping=True, length_penalty: float = 1.0):
+                device, early_stopping=True, length_penalty: float = 1.0, topk=None, update=None):
+    """``topk(logits [B * nb, vocab] fp32, run_sc [B, nb]) -> (top_lp [B, 2 nb], top_ix [B, 2 nb])``: optional fused ranking
+    (kzv_beam_topk on the GPU); None = the torch expression of the same thing below.
+    ``update``: optional fused bookkeeping (kzv_beam_update); with it the loop below is replaced by beam_search_fused."""
     import torch
+    if update is not None and topk is not None:
+        return beam_search_fused(step, reorder, batch, num_beams, max_len, vocab, pad_id, bos_id, eos_id, device, early_stopping,
+                                 length_penalty, topk, update)
     B, nb, K = batch, num_beams, 2 * num_beams
     prompt = 1                                                    # decoder prompt = [BOS]
     run_seq = torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=device)
@@ -65,11 +71,17 @@ def beam_search(step, reorder, batch: int, num_beams: int, max_len: int, vocab: 
     base = (torch.arange(B, device=device) * nb).view(B, 1)
     cur = prompt
     while True:
-        logp = torch.log_softmax(step(cur - 1, run_seq.view(B * nb, max_len)).float(), dim=-1)
-        acc = logp.view(B, nb, vocab) + run_sc.unsqueeze(-1)
+        raw = step(cur - 1, run_seq.view(B * nb, max_len))
+        if topk is not None:
+            top_lp, top_ix = topk(raw, run_sc)
+        else:
+            logp = torch.log_softmax(raw.float(), dim=-1)
+            acc = logp.view(B, nb, vocab) + run_sc.unsqueeze(-1)
         # top K of the nb * vocab continuations in two stages (the K best overall are among each beam's K best): one
         # single-block top-k per beam row instead of a multi-pass radix select over nb * vocab entries per batch element
-        if vocab > 4 * K:
+        if topk is not None:
+            pass
+        elif vocab > 4 * K:
             blp, bix = acc.topk(K, dim=2)                                  # [B, nb, K]
             top_lp, sel = blp.reshape(B, nb * K).topk(K, dim=1)
             top_ix = (bix + (torch.arange(nb, device=device) * vocab).view(1, nb, 1)).reshape(B, nb * K).gather(1, sel)
@@ -106,3 +118,72 @@ def beam_search(step, reorder, batch: int, num_beams: int, max_len: int, vocab: 
         reorder(rows, cur - 1)
     width = int(fin_len[:, 0].max())
     return fin_seq[:, 0, :width]
+
+
+def beam_search_fused(step, reorder, batch, num_beams, max_len, vocab, pad_id, bos_id, eos_id, device, early_stopping, length_penalty,
+                      topk, update, return_state=False):
+    """The same loop with the two device kernels: ``topk`` ranks the continuations, ``update(state, top_lp, top_ix, cur) -> (rows,
+    flags)`` does everything beam_search does between two steps (state: dict of the tensors below; token rows double-buffered).
+    One host synchronisation per step (the three counters of ``flags``)."""
+    import torch
+    B, nb = batch, num_beams
+    st = {"run_seq": [torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=device) for _ in range(2)],
+          "fin_seq": [torch.full((B, nb, max_len), pad_id, dtype=torch.int64, device=device) for _ in range(2)],
+          "run_sc": torch.zeros(B, nb, device=device), "fin_sc": torch.full((B, nb), NEG, device=device),
+          "fin_done": torch.zeros(B, nb, dtype=torch.uint8, device=device),
+          "fin_len": torch.full((B, nb), 1, dtype=torch.int64, device=device),
+          "unsat": torch.ones(B, dtype=torch.uint8, device=device), "cur_buf": 0}
+    for t in st["run_seq"] + st["fin_seq"]:
+        t[:, :, 0] = bos_id
+    st["run_sc"][:, 1:] = NEG
+    cur = 1
+    while True:
+        raw = step(cur - 1, st["run_seq"][st["cur_buf"]].view(B * nb, max_len))
+        top_lp, top_ix = topk(raw, st["run_sc"])
+        rows, flags = update(st, top_lp, top_ix, cur)
+        st["cur_buf"] ^= 1
+        cur += 1
+        f = flags.tolist()                                         # the one host synchronisation of the step
+        go_on = f[0] > 0 and not (f[1] == 0 and early_stopping is True) and f[2] > 0
+        if not go_on:
+            break
+        reorder(rows, cur - 1)
+    fin_seq = st["fin_seq"][st["cur_buf"]]
+    width = int(st["fin_len"][:, 0].max())
+    out = fin_seq[:, 0, :width]
+    return (out, st) if return_state else out
+
+
+def make_device_hooks(batch, num_beams, max_len, vocab, eos_id, early_stopping, length_penalty, device):
+    """(topk, update) for beam_search on the GPU: kzv_beam_topk and kzv_beam_update through the C ABI, on the current stream,
+    writing into buffers allocated here once."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    lib = L.load()
+    B, nb = batch, num_beams
+    top_lp = torch.empty(B, 2 * nb, dtype=torch.float32, device=device)
+    top_ix = torch.empty(B, 2 * nb, dtype=torch.int64, device=device)
+    rows_buf = torch.empty(B * nb, dtype=torch.int64, device=device)
+    flags_buf = torch.empty(3, dtype=torch.int32, device=device)
+    keep = {}
+
+    def topk(raw, run_sc):                # log_softmax + beam score + top 2 * nb per image in one launch
+        sc = run_sc.contiguous()
+        keep["sc"] = sc
+        L.check(lib.kzv_beam_topk(raw.data_ptr(), raw.stride(0), sc.data_ptr(), B, nb, vocab, 2 * nb, top_lp.data_ptr(), top_ix.data_ptr(),
+                                  L.stream_handle()), "beam_topk")
+        return top_lp, top_ix
+
+    def update(st, lp, ix, cur):          # everything between two decoder steps in one launch
+        a = st["cur_buf"]
+        bs = L.kzv_beam_state(batch=B, num_beams=nb, max_len=max_len, vocab=vocab, eos_id=eos_id,
+                              run_seq_in=st["run_seq"][a].data_ptr(), run_seq_out=st["run_seq"][a ^ 1].data_ptr(),
+                              fin_seq_in=st["fin_seq"][a].data_ptr(), fin_seq_out=st["fin_seq"][a ^ 1].data_ptr(),
+                              run_scores=st["run_sc"].data_ptr(), fin_scores=st["fin_sc"].data_ptr(), fin_done=st["fin_done"].data_ptr(),
+                              fin_len=st["fin_len"].data_ptr(), unsatisfied=st["unsat"].data_ptr())
+        L.check(lib.kzv_beam_update(C.byref(bs), lp.data_ptr(), ix.data_ptr(), cur, 1 if early_stopping is True else 0, float(length_penalty),
+                                    rows_buf.data_ptr(), flags_buf.data_ptr(), L.stream_handle()), "beam_update")
+        return rows_buf, flags_buf
+
+    return topk, update

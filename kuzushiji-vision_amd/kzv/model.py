@@ -344,6 +344,12 @@ class TrOCRModel:
                 state["valid"].copy_(state["valid"][rows])                # in place: the graph holds this buffer's address
                 L.check(lib.kzv_decode_reorder(self._h, rows.data_ptr(), n_keys, L.stream_handle()), "decode_reorder")
 
+        topk = update = None
+        if nb > 1 and nb <= 8 and self.device.type == "cuda" and os.environ.get("KZV_BEAM_TOPK", "1") != "0":
+            topk, update = BM.make_device_hooks(B, nb, Lh, c.vocab, c.eos_id, early_stopping, length_penalty, self.device)
+            if os.environ.get("KZV_BEAM_UPDATE", "1") == "0":
+                update = None
+
         try:
             with torch.cuda.stream(side):
                 if use_cache:
@@ -353,7 +359,7 @@ class TrOCRModel:
                     out = BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device)
                 else:
                     out = BM.beam_search(step, reorder, B, nb, Lh, c.vocab, c.pad_id, c.bos_id, c.eos_id, self.device,
-                                         early_stopping=early_stopping, length_penalty=length_penalty)
+                                         early_stopping=early_stopping, length_penalty=length_penalty, topk=topk, update=update)
             if graph:
                 cur.wait_stream(side)
                 for t_ in (out, step_logits, posids, tok_buf, state["valid"], px):

@@ -263,9 +263,12 @@ def test_kv_cached_step_equals_the_prefix_recompute(tmp_path):
     a = torch.empty(B, cfg.vocab, device="cuda"); b = torch.empty(B, cfg.vocab, device="cuda")
     valid = torch.zeros(B, Lh, dtype=torch.uint8, device="cuda")
     posids = torch.empty(B, dtype=torch.int32, device="cuda")
-    perm = torch.tensor([2, 0, 1, 5, 4, 3], device="cuda")
+    # beam-style re-parenting (row r continues from former row parents[r]): a permutation, then duplicated parents (rows that
+    # die out, rows that fork), then chains of both -- the cache rows never move, the attention follows a row table
+    parents = {3: [2, 0, 1, 5, 4, 3], 6: [0, 0, 2, 2, 5, 5], 7: [1, 0, 3, 2, 4, 4], 10: [5, 4, 3, 2, 1, 0], 11: [0, 0, 0, 3, 3, 3]}
     for t in range(Lh - 1):
-        if t == 6:          # beam-style re-ordering: row r continues from former row perm[r]
+        if t in parents:
+            perm = torch.tensor(parents[t], device="cuda")
             ids = ids[perm].contiguous(); valid = valid[perm].contiguous()
             L.check(lib.kzv_decode_reorder(m._h, perm.data_ptr(), t, L.stream_handle()), "reorder")
         tok = ids[:, t].contiguous()

@@ -331,3 +331,33 @@ def test_attention_other_head_dims_fwd_bwd(lib, B, heads, S, D, drop):
     want_g = x.grad.permute(1, 3, 0, 2, 4).reshape(B * S, 3 * H)
     err = (dqkv.float() - want_g).abs().max().item()
     assert err < 3e-2 * want_g.abs().max().item() + 2e-3, err
+
+
+@pytest.mark.parametrize("B,nb,V", [(1, 1, 41), (5, 2, 157), (7, 3, 1000), (256, 4, 4300), (3, 8, 4300)])
+def test_beam_topk_matches_log_softmax_plus_topk(lib, B, nb, V):
+    """kzv_beam_topk against the torch expression it replaces in kzv/beam.py (log_softmax + beam score, top 2 * nb of the
+    nb * V continuations per image, best first); with a padded row stride, dead beams (score -1e9) and exact ties."""
+    torch.manual_seed(B * V + nb)
+    K, ld = 2 * nb, V + 4
+    buf = torch.randn(B * nb, ld, device=DEV) * 3
+    logits = buf[:, :V]
+    sc = torch.randn(B, nb, device=DEV)
+    sc[0, 1:] = -1.0e9                                    # first step of a generation: only beam 0 is live
+    out_lp = torch.empty(B, K, device=DEV)
+    out_ix = torch.empty(B, K, dtype=torch.int64, device=DEV)
+    L.check(lib.kzv_beam_topk(logits.data_ptr(), ld, sc.data_ptr(), B, nb, V, K, out_lp.data_ptr(), out_ix.data_ptr(), _st()), "beam_topk")
+    torch.cuda.synchronize()
+    acc = (torch.log_softmax(logits.float(), dim=-1).view(B, nb, V) + sc.unsqueeze(-1)).view(B, nb * V)
+    ref_lp, ref_ix = acc.topk(K, dim=1)
+    assert torch.equal(out_ix, ref_ix)
+    assert (out_lp - ref_lp).abs().max().item() < 2e-5 * max(1.0, ref_lp[ref_lp > -1e8].abs().max().item())
+    # ties: identical rows with identical scores -> the smaller flat index (beam * V + token) first
+    if nb > 1:
+        buf[:nb] = buf[0]
+        sc[0] = 0.25
+        L.check(lib.kzv_beam_topk(logits.data_ptr(), ld, sc.data_ptr(), B, nb, V, K, out_lp.data_ptr(), out_ix.data_ptr(), _st()), "beam_topk")
+        torch.cuda.synchronize()
+        best = int(logits[0].argmax())
+        assert out_ix[0, :nb].tolist() == [k * V + best for k in range(nb)]
+        assert float(out_lp[0, 0]) == float(out_lp[0, nb - 1])
+    assert lib.kzv_beam_topk(logits.data_ptr(), ld, sc.data_ptr(), B, 9, V, 16, out_lp.data_ptr(), out_ix.data_ptr(), _st()) != 0      # > 8 beams
