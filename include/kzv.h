@@ -127,6 +127,14 @@ int kzv_decode_reorder(kzv_model* m, const int64_t* d_rows, int len, void* strea
  * equal scores rank by the smaller flat index.  d_top_scores [batch, k] fp32, d_top_index [batch, k] int64 = beam * vocab + token. */
 int kzv_beam_topk(const float* d_logits, int64_t ld, const float* d_beam_scores, int batch, int num_beams, int vocab, int k,
                   float* d_top_scores, int64_t* d_top_index, void* stream);
+/* The inputs of decoder step t from the token table d_ids [batch, ld_ids]: d_tokens [batch] = column t, d_posids [batch] = its
+ * RoBERTa position id (t + 1 + pad_id, or pad_id for padding), d_valid[:, t] = token != pad. */
+int kzv_decode_prep(const int64_t* d_ids, int64_t ld_ids, int t, int pad_id, int batch, int64_t* d_tokens, uint8_t* d_valid, int64_t ld_valid,
+                    int32_t* d_posids, void* stream);
+/* Greedy token selection (num_beams = 1): d_ids[:, t + 1] = argmax of the row (first maximum), or pad_id once the sequence has
+ * emitted eos_id (d_done [batch] is read and updated); d_flags[0] = sequences still running after this step. */
+int kzv_greedy_update(const float* d_logits, int64_t ld, int vocab, int64_t* d_ids, int64_t ld_ids, int t, uint8_t* d_done, int batch,
+                      int pad_id, int eos_id, int32_t* d_flags, void* stream);
 /* One beam-search step's bookkeeping on the device -- what transformers' GenerationMixin._beam_search does between two decoder
  * steps (running beams of the next step, finished list, early-stop heuristic; kzv/beam.py states it in torch ops and is pinned
  * against HF on the CPU).  State arrays live in caller memory for the whole generation; token rows are double-buffered (the

@@ -394,6 +394,54 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const BeamUpd p) {
     }
 }
 
+// inputs of decoder step t from the token table: newest token, its RoBERTa position id (HF modeling_roberta.py:142-155: t + 1 +
+// pad_id for a real token, pad_id for padding) and the key-usable flag of column t -- six small torch kernels otherwise
+__global__ void decode_prep_kernel(const int64_t* __restrict__ ids, int64_t ld_ids, int t, int pad, int B, int64_t* __restrict__ tok,
+                                   unsigned char* __restrict__ valid, int64_t ld_valid, int* __restrict__ posids) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t v = ids[(int64_t)b * ld_ids + t];
+    const bool live = v != pad;
+    tok[b] = v;
+    valid[(int64_t)b * ld_valid + t] = live ? 1 : 0;
+    posids[b] = live ? t + 1 + pad : pad;
+}
+
+// greedy token selection of one sequence (the num_beams = 1 branch of HF _sample: argmax, padding once the sequence has ended):
+// the first index of the row maximum, like torch.argmax
+__global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restrict__ logits, int64_t ld, int V, int64_t* __restrict__ ids, int64_t ld_ids,
+                                                            int t, unsigned char* __restrict__ done, int pad, int eos, int* __restrict__ flags) {
+    __shared__ float s_v[4]; __shared__ int s_i[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* row = logits + (int64_t)b * ld;
+    constexpr int E = 8;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int v0 = tid; v0 < V; v0 += 256 * E) {
+        float x[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = row[min(v0 + e * 256, V - 1)];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const int v = v0 + e * 256; if (v < V && x[e] > bv) { bv = x[e]; bi = v; } }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_v[w] = bv; s_i[w] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (s_v[q] > bv || (s_v[q] == bv && s_i[q] < bi)) { bv = s_v[q]; bi = s_i[q]; }
+        const bool was = done[b] != 0;
+        const int nxt = was ? pad : bi;
+        ids[(int64_t)b * ld_ids + t + 1] = nxt;
+        const bool now = was || nxt == eos;
+        done[b] = now ? 1 : 0;
+        if (!now) atomicAdd(flags, 1);
+    }
+}
+
 __global__ void step_inc_kernel(int* t) { *t += 1; }
 
 }  // namespace
@@ -472,4 +520,20 @@ extern "C" int kzv_beam_update(const kzv_beam_state* st, const float* d_top_scor
               (float)pow((double)(cur + 1 - 1), (double)length_penalty), (float)pow((double)(cur + 1 - 1), (double)length_penalty)};
     hipLaunchKernelGGL(beam_update_kernel, dim3(st->batch), dim3(64), 0, s, p);
     return kzv_check_launch("beam_update");
+}
+
+extern "C" int kzv_decode_prep(const int64_t* d_ids, int64_t ld_ids, int t, int pad_id, int batch, int64_t* d_tokens, uint8_t* d_valid, int64_t ld_valid,
+                               int32_t* d_posids, void* stream) {
+    if (!d_ids || !d_tokens || !d_valid || !d_posids || batch < 1 || t < 0 || t >= ld_ids || t >= ld_valid) return kzv_fail(KZV_E_ARG, "decode_prep: bad arguments");
+    hipLaunchKernelGGL(decode_prep_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_ids, ld_ids, t, pad_id, batch, d_tokens, d_valid, ld_valid, d_posids);
+    return kzv_check_launch("decode_prep");
+}
+
+extern "C" int kzv_greedy_update(const float* d_logits, int64_t ld, int vocab, int64_t* d_ids, int64_t ld_ids, int t, uint8_t* d_done, int batch,
+                                 int pad_id, int eos_id, int32_t* d_flags, void* stream) {
+    if (!d_logits || !d_ids || !d_done || !d_flags || batch < 1 || vocab < 1 || ld < vocab || t < 0 || t + 1 >= ld_ids) return kzv_fail(KZV_E_ARG, "greedy_update: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d_flags, 0, sizeof(int), s) != hipSuccess) return kzv_fail(KZV_E_HIP, "greedy_update: memset");
+    hipLaunchKernelGGL(greedy_update_kernel, dim3(batch), dim3(256), 0, s, d_logits, ld, vocab, d_ids, ld_ids, t, d_done, pad_id, eos_id, d_flags);
+    return kzv_check_launch("greedy_update");
 }

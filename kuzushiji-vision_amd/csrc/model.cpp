@@ -862,6 +862,17 @@ static int ensure_kv_cache(kzv_model* m) {
 
 // one decoder step for the newest token of every sequence; tptr != nullptr: the step index is read from device memory
 // (graph replay), `t` is then only the host's copy for argument checks
+// a decoder sub-layer's output GEMM and the LayerNorm after it.  (Fusing the two for N = 256 -- one 16-wave workgroup per 16
+// rows, wave w finishing row w -- was built and measured in round 2: bit-identical, and 100 us per step SLOWER: 16..64 large
+// workgroups lose more to launch and single-CU load paths than the 19 saved ~5-us LayerNorm launches return.)
+static int gemm_ln(kzv_model* m, const bf16_t* A, int64_t lda, const W16& w, int M, int K, const float* bias, const float* resid, bool gelu,
+                   float* tmp32, bf16_t* aux_tmp, const float* gamma, const float* beta, bf16_t* y16, float* y32, float* stats, hipStream_t s) {
+    const int Hd = m->Hd;
+    if (gelu) KZV_TRY(gemm(A, lda, w, false, M, Hd, K, Hd, bias, tmp32, Hd, KZV_EPI_GELU_F32, s, nullptr, aux_tmp, Hd));
+    else KZV_TRY(gemm(A, lda, w, false, M, Hd, K, Hd, bias, tmp32, Hd, KZV_EPI_RESID, s, resid, nullptr, 0, 0.f, 0));
+    return kzv_ln_fwd_ex(tmp32, gamma, beta, y16, y32, stats, M, Hd, m->c.ln_eps, 1, 0, 0.f, 0, s);
+}
+
 static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const int* tptr, const unsigned char* d_valid,
                             int64_t ld_valid, float* d_logits, hipStream_t s) {
     const kzv_config& c = m->c;
@@ -883,20 +894,16 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
         KZV_TRY(kzv_attn_decode(a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, cache + (int64_t)(2 * i) * plane, cache + (int64_t)(2 * i + 1) * plane,
                                 (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr, 1,
                                 m->rt_cur >= 0 ? m->rowtab[m->rt_cur] : nullptr, T));
-        KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, B, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0, 0.f, 0));
-        KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, B, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm_ln(m, a.ctx, Hd, m->w_do[i], B, Hd, P + d.ob, x, false, a.s1, nullptr, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, s));
         KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
         KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd,
                                 (int64_t)m->npa * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s, nullptr, B / m->Be));
-        KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, B, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0, 0.f, 0));
-        KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, B, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm_ln(m, a.cctx, Hd, m->w_dco[i], B, Hd, P + d.cob, a.x1, false, a.s2, nullptr, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, s));
         KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, B, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
-        KZV_TRY(gemm(a.act, Fd, m->w_dfc2[i], false, B, Hd, Fd, Hd, P + d.fc2b, a.s3, Hd, KZV_EPI_RESID, s, a.x2, nullptr, 0, 0.f, 0));
-        KZV_TRY(kzv_ln_fwd_ex(a.s3, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, B, Hd, eps, 1, 0, 0.f, 0, s));
+        KZV_TRY(gemm_ln(m, a.act, Fd, m->w_dfc2[i], B, Fd, P + d.fc2b, a.x2, false, a.s3, nullptr, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, s));
         x = a.x3; xh = a.x3h;
     }
-    KZV_TRY(gemm(xh, Hd, m->w_hd, false, B, Hd, Hd, Hd, P + m->hd_b, m->hd_gelu, Hd, KZV_EPI_GELU_F32, s, nullptr, m->hd_pre, Hd));
-    KZV_TRY(kzv_ln_fwd_ex(m->hd_gelu, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, B, Hd, eps, 1, 0, 0.f, 0, s));
+    KZV_TRY(gemm_ln(m, xh, Hd, m->w_hd, B, Hd, P + m->hd_b, nullptr, true, m->hd_gelu, m->hd_pre, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, s));
     KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, B, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
     KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s));
     return KZV_OK;

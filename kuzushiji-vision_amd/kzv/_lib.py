@@ -130,6 +130,9 @@ SYMBOLS = {
     "kzv_decode_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kzv_decode_step_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kzv_decode_reorder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "kzv_decode_prep": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "kzv_greedy_update": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
     "kzv_beam_update": (C.c_int, [C.POINTER(kzv_beam_state), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kzv_beam_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kzv_lanczos_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),

@@ -324,12 +324,11 @@ class TrOCRModel:
                 L.check(lib.kzv_set_active_length(self._h, t + 1), "set_active_length")   # later positions are not needed
                 L.check(lib.kzv_decode_logits(self._h, ids.data_ptr(), t, step_logits.data_ptr(), L.stream_handle()), "decode_logits")
                 return step_logits
-            tok_buf.copy_(ids[:, t])
-            live = tok_buf != c.pad_id
             valid = state["valid"]
-            valid[:, t] = live.to(torch.uint8)
-            # RoBERTa position ids (modeling_roberta.py:142-155): cumsum of non-pad tokens + pad_id; prefixes never hold pads
-            posids.copy_(torch.where(live, torch.full_like(tok_buf, t + 1 + c.pad_id), torch.full_like(tok_buf, c.pad_id)).to(torch.int32))
+            # newest token, RoBERTa position id (modeling_roberta.py:142-155: cumsum of non-pad tokens + pad_id; prefixes never
+            # hold pads) and the key-usable flag of column t, in one launch
+            L.check(lib.kzv_decode_prep(ids.data_ptr(), ids.stride(0), t, c.pad_id, BB, tok_buf.data_ptr(), valid.data_ptr(), Lh,
+                                        posids.data_ptr(), L.stream_handle()), "decode_prep")
             if graph:
                 L.check(lib.kzv_decode_step_graph(self._h, tok_buf.data_ptr(), posids.data_ptr(), valid.data_ptr(), Lh, step_logits.data_ptr(),
                                                   L.stream_handle()), "decode_step_graph")
@@ -356,7 +355,8 @@ class TrOCRModel:
                     L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")
                     L.check(lib.kzv_decode_begin(self._h, L.stream_handle()), "decode_begin")
                 if nb == 1:
-                    out = BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device)
+                    gupd = BM.make_greedy_hook(B, c.vocab, c.pad_id, c.eos_id, self.device) if self.device.type == "cuda" and os.environ.get("KZV_BEAM_TOPK", "1") != "0" else None
+                    out = BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device, update=gupd)
                 else:
                     out = BM.beam_search(step, reorder, B, nb, Lh, c.vocab, c.pad_id, c.bos_id, c.eos_id, self.device,
                                          early_stopping=early_stopping, length_penalty=length_penalty, topk=topk, update=update)
