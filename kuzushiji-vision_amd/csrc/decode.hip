@@ -84,11 +84,33 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
         if (j >= nkeys) return (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         return *(const bf16x8*)((j == append_at ? fresh : base + (G > 1 ? 0 : roff[G > 1 ? 0 : i]) + (int64_t)j * p.kj) + c * 8);
     };
+    // key-usable flags of this lane's keys: loaded up front and unconditionally (clamped index) -- inside the score loop each one
+    // sat in its own branch behind an s_waitcnt vmcnt(0), i.e. 24 serial round trips per self-attention call
+    bool kok[G][NI];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) kok[g][i] = true;
+    if (p.valid) {
+        unsigned char vb[G][NI];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) vb[g][i] = p.valid[(int64_t)(b0 + g) * p.ldvalid + min(8 * i + r, (int)p.ldvalid - 1)];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) kok[g][i] = vb[g][i] != 0;
+    }
     float sc[G][NI];
     float mx[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
-    constexpr int CH = 8;                          // rows in flight: 8 wave-instructions = 64 keys
+    // rows in flight: one sequence per wave and <= 192 keys: ALL keys and ALL values are requested before the first score is
+    // computed (the kernel is then three dependent round trips long: query / tables, keys + values, output); otherwise 64 keys
+    constexpr bool ALL = G == 1 && NI <= 24;
+    constexpr int CH = ALL ? NI : 8;
+    bf16x8 vpre[ALL ? NI : 1];
 #pragma unroll
     for (int i0 = 0; i0 < NI; i0 += CH) {
         if (i0 * 8 >= nkeys) {                     // wave-uniform: nothing left
@@ -101,6 +123,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
         bf16x8 kk[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) kk[u] = row(Kb, knew, i0 + u);
+        if constexpr (ALL) {
+#pragma unroll
+            for (int u = 0; u < NI; ++u) vpre[u] = row(Vb, vnew, u);
+        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int j = 8 * (i0 + u) + r;
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a += qc[g][e] * kf[e];
                 a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-                const bool ok = j < nkeys && (!p.valid || p.valid[(int64_t)(b0 + g) * p.ldvalid + j]);
+                const bool ok = j < nkeys && kok[g][i0 + u];
                 sc[g][i0 + u] = ok ? a : -INFINITY;
                 mx[g] = fmaxf(mx[g], sc[g][i0 + u]);
             }
@@ -140,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
         if (i0 * 8 >= nkeys) continue;
         bf16x8 vv[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) vv[u] = row(Vb, vnew, i0 + u);
+        for (int u = 0; u < CH; ++u) { if constexpr (ALL) vv[u] = vpre[u]; else vv[u] = row(Vb, vnew, i0 + u); }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             float vf[8];
