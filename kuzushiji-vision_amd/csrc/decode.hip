@@ -22,7 +22,7 @@ struct DecAttnP {
     float scale;
     const int* tptr;                              // non-null: the step index t lives in device memory (graph replay): nkeys = t + 1, append_at = t
     int group;                                    // keys / values of sequence b live at batch index b / group (beams sharing one image's cross-attention K/V)
-    const int* rows; int64_t ldrows;              // non-null (beam search): cached key j of sequence b lives in cache row rows[b * ldrows + j]
+    int* rows; int64_t ldrows;                    // non-null (beam search): cached key j of sequence b lives in cache row rows[b * ldrows + j]
 };
 
 // One WAVE per (G sequences, head), no LDS and no barrier.  Every global access is a wave-instruction over 8 key (or value) rows x
@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
     if (append_at >= 0) {                         // lane d copies dimension d of the new key and value into the cache
         Kb[(int64_t)append_at * p.kj + lane] = knew[lane];
         Vb[(int64_t)append_at * p.kj + lane] = vnew[lane];
+        // ... and the row table learns where it went (own row): steps that are not followed by a re-parenting leave it complete.
+        // No wave reads entry [b][append_at] during this step (that key comes from the projection output).
+        if (G == 1 && p.rows && lane == 0 && h == 0) p.rows[(int64_t)b * p.ldrows + append_at] = b;
     }
     float qc[G][8];
 #pragma unroll
@@ -480,7 +483,7 @@ int kzv_step_inc(int* d_t, hipStream_t s) {
 // tptr != nullptr: self-attention of graph-replayed step `*tptr` (nkeys = the cache capacity, which picks the kernel)
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
-                    int append_at, hipStream_t s, const int* tptr, int group, const int* rows, int64_t ldrows) {
+                    int append_at, hipStream_t s, const int* tptr, int group, int* rows, int64_t ldrows) {
     if (nkeys < 1 || nkeys > 320) return kzv_fail(KZV_E_ARG, "attn_decode: 1..320 keys");
     if (ldq % 8 || ldo % 8 || (knew && ldnew % 8)) return kzv_fail(KZV_E_ARG, "attn_decode: rows must be 16-byte aligned");
     if (group < 1 || (append_at >= 0 && group != 1)) return kzv_fail(KZV_E_ARG, "attn_decode: shared keys cannot be appended to");
