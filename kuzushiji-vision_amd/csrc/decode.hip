@@ -9,13 +9,14 @@
 #include "kzv_host.h"
 #include "kzv_kernels.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
 struct DecAttnP {
     const bf16_t* q; int64_t ldq;                 // [B, ldq], head h at column h*64
     const bf16_t* knew; const bf16_t* vnew; int64_t ldnew;   // this step's key/value rows [B, ldnew] (self-attention) or null
-    bf16_t* K; bf16_t* V; int64_t kb, kj;         // key j of sequence b: K + b*kb + j*kj + h*64 (same strides for V)
+    bf16_t* K; bf16_t* V; int64_t kb, kj, kh;     // key j, head h of sequence b: K + b*kb + h*kh + j*kj (same strides for V)
     const unsigned char* valid; int64_t ldvalid;  // [B, ldvalid]: key j usable (null: all)
     bf16_t* out; int64_t ldo;
     int nkeys, append_at, heads;                  // append_at >= 0: write knew/vnew at key index append_at first
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
     if (unit >= nunits) return;
     const int b0 = (unit / p.heads) * G, h = unit - (unit / p.heads) * p.heads, lane = threadIdx.x & 63;
     const int b = b0;                                              // G == 1: the sequence
-    bf16_t* Kb = p.K + (int64_t)(b0 / p.group) * p.kb + h * 64;
-    bf16_t* Vb = p.V + (int64_t)(b0 / p.group) * p.kb + h * 64;
+    bf16_t* Kb = p.K + (int64_t)(b0 / p.group) * p.kb + h * p.kh;
+    bf16_t* Vb = p.V + (int64_t)(b0 / p.group) * p.kb + h * p.kh;
     const int tdev = p.tptr ? *p.tptr : 0;
     const int nkeys = p.tptr ? min(tdev + 1, 8 * NI) : p.nkeys;
     const int append_at = (G > 1) ? -1 : (p.tptr ? min(tdev, 8 * NI - 1) : p.append_at);
@@ -109,11 +110,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
     float mx[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
-    // rows in flight: one sequence per wave and <= 192 keys: ALL keys and ALL values are requested before the first score is
-    // computed (the kernel is then three dependent round trips long: query / tables, keys + values, output); otherwise 64 keys
-    constexpr bool ALL = G == 1 && NI <= 24;
-    constexpr int CH = ALL ? NI : 8;
-    bf16x8 vpre[ALL ? NI : 1];
+    // rows in flight: 8 wave-instructions = 64 keys.  (Requesting ALL key and value rows before the first score -- 225
+    // registers -- changed nothing for 1,024 waves and cost the 4,096-wave beam step 6 ms per generation: occupancy.)
+    constexpr int CH = 8;
 #pragma unroll
     for (int i0 = 0; i0 < NI; i0 += CH) {
         if (i0 * 8 >= nkeys) {                     // wave-uniform: nothing left
@@ -126,10 +125,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
         bf16x8 kk[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) kk[u] = row(Kb, knew, i0 + u);
-        if constexpr (ALL) {
-#pragma unroll
-            for (int u = 0; u < NI; ++u) vpre[u] = row(Vb, vnew, u);
-        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int j = 8 * (i0 + u) + r;
@@ -169,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
         if (i0 * 8 >= nkeys) continue;
         bf16x8 vv[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) { if constexpr (ALL) vv[u] = vpre[u]; else vv[u] = row(Vb, vnew, i0 + u); }
+        for (int u = 0; u < CH; ++u) vv[u] = row(Vb, vnew, i0 + u);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             float vf[8];
@@ -194,16 +189,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecAttnP p, cons
     }
 }
 
-// beam re-ordering: dst[l][b][j][:] = src[l][idx[b]][j][:] for j < len (16-byte chunks)
-__global__ __launch_bounds__(256) void kv_reorder_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int64_t* __restrict__ idx,
-                                                         int B, int Tmax, int len, int chunks_per_row, int64_t layer_stride16) {
-    const int64_t per_b = (int64_t)len * chunks_per_row;
+// Cross-attention keys / values for the generation steps: [layer][K|V][image][head][key][64] from the projection output
+// [image * keys][layer][K|V][head][64] (one GEMM row per patch token).  There a head's key rows are 128-byte pieces 6 KB
+// apart (17 us per call at 256 images: 2.5 TB/s); here each (image, head) streams one contiguous block.  Once per generation.
+__global__ __launch_bounds__(256) void cross_relayout_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int images, int keys, int heads,
+                                                             int layers2, int64_t total16) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)B * per_b) return;
-    const int b = (int)(t / per_b);
-    const int64_t r = t - (int64_t)b * per_b;
-    const int64_t lo = (int64_t)blockIdx.y * layer_stride16;
-    dst[lo + (int64_t)b * Tmax * chunks_per_row + r] = src[lo + idx[b] * (int64_t)Tmax * chunks_per_row + r];
+    if (t >= total16) return;
+    int64_t r = t;                                  // dst order: [l2][img][h][key][8 chunks]
+    const int c = r & 7; r >>= 3;
+    const int key = r % keys; r /= keys;
+    const int h = r % heads; r /= heads;
+    const int img = r % images; r /= images;
+    const int l2 = (int)r;
+    dst[t] = src[(((int64_t)img * keys + key) * layers2 + l2) * heads * 8 + h * 8 + c];
 }
 
 // beam re-parenting without moving the cache: dst[b][j] = src[parent[b]][j] for the keys written before this step, and the key
@@ -483,14 +482,15 @@ int kzv_step_inc(int* d_t, hipStream_t s) {
 // tptr != nullptr: self-attention of graph-replayed step `*tptr` (nkeys = the cache capacity, which picks the kernel)
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
-                    int append_at, hipStream_t s, const int* tptr, int group, int* rows, int64_t ldrows) {
+                    int append_at, hipStream_t s, const int* tptr, int group, int* rows, int64_t ldrows, int64_t kh) {
     if (nkeys < 1 || nkeys > 320) return kzv_fail(KZV_E_ARG, "attn_decode: 1..320 keys");
     if (ldq % 8 || ldo % 8 || (knew && ldnew % 8)) return kzv_fail(KZV_E_ARG, "attn_decode: rows must be 16-byte aligned");
     if (group < 1 || (append_at >= 0 && group != 1)) return kzv_fail(KZV_E_ARG, "attn_decode: shared keys cannot be appended to");
     if (kj % 8) return kzv_fail(KZV_E_ARG, "attn_decode: key rows must be 16-byte aligned");
     if (rows && group != 1) return kzv_fail(KZV_E_ARG, "attn_decode: a row table and shared keys exclude each other");
     if (rows && (int64_t)B * kb >= (1ll << 31)) return kzv_fail(KZV_E_ARG, "attn_decode: cache too large for 32-bit row offsets");
-    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr, group, rows, ldrows};
+    if (kh % 8) return kzv_fail(KZV_E_ARG, "attn_decode: head stride must be 16-byte aligned");
+    DecAttnP p{q, ldq, knew, vnew, ldnew, K, V, kb, kj, kh, valid, ldvalid, out, ldo, nkeys, append_at, heads, 0.125f, tptr, group, rows, ldrows};
     // beams of one image (group > 1, shared keys): G of them per wave, G = the largest of 4, 3, 2 dividing the group
     const int G = group % 4 == 0 ? 4 : group % 3 == 0 ? 3 : group % 2 == 0 ? 2 : 1;
     const int nunits = (B / G) * heads;
@@ -507,12 +507,11 @@ int kzv_kv_rows(const int* src, int* dst, const int64_t* parent, int B, int ld, 
     return kzv_check_launch("kv_rows");
 }
 
-int kzv_kv_reorder(const bf16_t* src, bf16_t* dst, const int64_t* idx, int layers2, int B, int Tmax, int len, int Hd, hipStream_t s) {
-    const int cpr = Hd / 8;                       // 16-byte chunks per cache row
-    const int64_t total = (int64_t)B * len * cpr;
-    hipLaunchKernelGGL(kv_reorder_kernel, dim3((unsigned)((total + 255) / 256), layers2), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, idx,
-                       B, Tmax, len, cpr, (int64_t)B * Tmax * cpr);
-    return kzv_check_launch("kv_reorder");
+int kzv_cross_relayout(const bf16_t* src, bf16_t* dst, int images, int keys, int heads, int layers2, hipStream_t s) {
+    const int64_t total16 = (int64_t)layers2 * images * heads * keys * 8;
+    hipLaunchKernelGGL(cross_relayout_kernel, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, images, keys, heads,
+                       layers2, total16);
+    return kzv_check_launch("cross_relayout");
 }
 
 extern "C" int kzv_beam_topk(const float* d_logits, int64_t ld, const float* d_beam_scores, int batch, int num_beams, int vocab, int k,

@@ -58,7 +58,7 @@ int kzv_sqnorm(const float* g, int64_t n, float* out1, float* scratch, hipStream
 // decode.hip (KV-cached generation step)
 int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16_t* vnew, int64_t ldnew, bf16_t* K, bf16_t* V, int64_t kb,
                     int64_t kj, const unsigned char* valid, int64_t ldvalid, bf16_t* out, int64_t ldo, int B, int heads, int nkeys,
-                    int append_at, hipStream_t s, const int* tptr = nullptr, int group = 1, int* rows = nullptr, int64_t ldrows = 0);
+                    int append_at, hipStream_t s, const int* tptr = nullptr, int group = 1, int* rows = nullptr, int64_t ldrows = 0, int64_t kh = 64);
 int kzv_kv_rows(const int* src, int* dst, const int64_t* parent, int B, int ld, int len, hipStream_t s);
 int kzv_step_inc(int* d_t, hipStream_t s);
-int kzv_kv_reorder(const bf16_t* src, bf16_t* dst, const int64_t* idx, int layers2, int B, int Tmax, int len, int Hd, hipStream_t s);
+int kzv_cross_relayout(const bf16_t* src, bf16_t* dst, int images, int keys, int heads, int layers2, hipStream_t s);

@@ -82,6 +82,8 @@ struct kzv_model {
     bf16_t* kvc[2] = {nullptr, nullptr}; int kv_cur = 0, kvB = 0, kvT = 0;
     // beam re-parenting by indirection: rowtab[x][b][j] = cache row holding key j of sequence b; rt_cur = -1: identity (no table)
     int* rowtab[2] = {nullptr, nullptr}; int rt_cur = -1;
+    // cross-attention K/V re-laid out for the generation steps ([layer][K|V][image][head][key][64]); rebuilt when the encoder ran
+    bf16_t* ckv_dec = nullptr; size_t ckv_dec_bytes = 0; bool ckv_dec_ok = false;
     // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
     int* d_t = nullptr;
     hipGraphExec_t dgraph[3] = {nullptr, nullptr, nullptr};          // one per row table in use: none, rowtab[0], rowtab[1]
@@ -444,7 +446,7 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         KZV_TRY(gemm(m->enc_out, He, m->w_proj, false, Mp, Hd, He, Hd, P + m->proj_b, m->proj_out, Hd, KZV_EPI_BF16, s));
     // cross-attention K/V of every decoder layer in one GEMM
     KZV_TRY(gemm(m->proj_out, Hd, m->w_ckv, false, Mp, CK, Hd, CK, P + m->ckv_b, m->crosskv, CK, KZV_EPI_BF16, s));
-    m->have_enc = true; m->Be = B;
+    m->have_enc = true; m->Be = B; m->ckv_dec_ok = false;
     }   // run_encoder
     if (!run_decoder) return KZV_OK;
     B = m->B;
@@ -683,6 +685,7 @@ extern "C" int kzv_model_destroy(kzv_model* m) {
         for (int i = 0; i < 4; ++i) if (m->ev_done[i]) (void)hipEventDestroy(m->ev_done[i]);
         for (int i = 0; i < 2; ++i) if (m->kvc[i]) (void)hipFree(m->kvc[i]);
         for (int i = 0; i < 2; ++i) if (m->rowtab[i]) (void)hipFree(m->rowtab[i]);
+        if (m->ckv_dec) (void)hipFree(m->ckv_dec);
         for (int i = 0; i < 3; ++i) if (m->dgraph[i]) (void)hipGraphExecDestroy(m->dgraph[i]);
     }
     delete m;
@@ -860,6 +863,22 @@ static int ensure_kv_cache(kzv_model* m) {
     return KZV_OK;
 }
 
+// the decode-layout copy of the cross-attention K/V of the images encoded last (once per generation)
+static int ensure_cross_layout(kzv_model* m, hipStream_t s) {
+    if (m->ckv_dec_ok) return KZV_OK;
+    const size_t bytes = (size_t)m->Ld * 2 * m->Be * m->npa * m->Hd * sizeof(bf16_t);
+    if (bytes > m->ckv_dec_bytes) {
+        if (m->ckv_dec) (void)hipFree(m->ckv_dec);
+        m->ckv_dec = nullptr; m->ckv_dec_bytes = 0;
+        if (hipMalloc((void**)&m->ckv_dec, bytes) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: cross K/V copy allocation (%zu bytes)", bytes);
+        m->ckv_dec_bytes = bytes;
+        for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
+    }
+    KZV_TRY(kzv_cross_relayout(m->crosskv, m->ckv_dec, m->Be, m->npa, m->c.dec_heads, 2 * m->Ld, s));
+    m->ckv_dec_ok = true;
+    return KZV_OK;
+}
+
 // one decoder step for the newest token of every sequence; tptr != nullptr: the step index is read from device memory
 // (graph replay), `t` is then only the host's copy for argument checks
 // a decoder sub-layer's output GEMM and the LayerNorm after it.  (Fusing the two for N = 256 -- one 16-wave workgroup per 16
@@ -879,7 +898,6 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
     const int B = m->B, Hd = m->Hd, Fd = m->Fd, T = m->T;
     float* P = m->P;
     const float eps = c.ln_eps;
-    const int CK = m->Ld * 2 * Hd;
     KzvRowsScope rows_scope;                     // M = B rows: every GEMM of the step takes the few-rows kernel (gemm_rows.hip)
     bf16_t* cache = m->kvc[m->kv_cur];
     const int64_t plane = (int64_t)B * T * Hd;  // one layer's K (or V) cache
@@ -892,12 +910,15 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
         const DecLayerP& d = m->dp[i];
         KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, B, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
         KZV_TRY(kzv_attn_decode(a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, cache + (int64_t)(2 * i) * plane, cache + (int64_t)(2 * i + 1) * plane,
-                                (int64_t)T * Hd, Hd, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr, 1,
-                                m->rt_cur >= 0 ? m->rowtab[m->rt_cur] : nullptr, T));
+                                (int64_t)T * Hd, 64, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr, 1,
+                                m->rt_cur >= 0 ? m->rowtab[m->rt_cur] : nullptr, T, (int64_t)T * 64));      // cache rows: [head][T][64]
         KZV_TRY(gemm_ln(m, a.ctx, Hd, m->w_do[i], B, Hd, P + d.ob, x, false, a.s1, nullptr, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, s));
         KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
-        KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd,
-                                (int64_t)m->npa * CK, CK, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s, nullptr, B / m->Be));
+        {
+            const int64_t img = (int64_t)m->npa * Hd, plane2 = (int64_t)m->Be * img;      // [layer][K|V][image][head][key][64]
+            KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->ckv_dec + (int64_t)(2 * i) * plane2, m->ckv_dec + (int64_t)(2 * i + 1) * plane2,
+                                    img, 64, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s, nullptr, B / m->Be, nullptr, 0, (int64_t)m->npa * 64));
+        }
         KZV_TRY(gemm_ln(m, a.cctx, Hd, m->w_dco[i], B, Hd, P + d.cob, a.x1, false, a.s2, nullptr, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, s));
         KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, B, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
         KZV_TRY(gemm_ln(m, a.act, Fd, m->w_dfc2[i], B, Fd, P + d.fc2b, a.x2, false, a.s3, nullptr, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, s));
@@ -923,6 +944,7 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
     if (t < 0 || t >= m->T) return kzv_fail(KZV_E_ARG, "decode_step: step outside 0..T-1");
     KZV_TRY(ensure_kv_cache(m));
     if (t == 0) m->rt_cur = -1;                 // a new generation: no beam has been re-parented yet
+    KZV_TRY(ensure_cross_layout(m, (hipStream_t)stream));
     m->train = false; m->have_fwd = false;      // decoder activations are overwritten: no backward after this
     return decode_step_body(m, d_tokens, d_posids, t, nullptr, d_valid, ld_valid, d_logits, (hipStream_t)stream);
 }
@@ -930,6 +952,7 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
 extern "C" int kzv_decode_begin(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_begin: model not bound");
     KZV_TRY(ensure_kv_cache(m));
+    if (m->have_enc) KZV_TRY(ensure_cross_layout(m, (hipStream_t)stream));
     m->rt_cur = -1;                              // a new generation: every sequence reads its own cache row
     if (hipMemsetAsync(m->d_t, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_begin: memset");
     return KZV_OK;
@@ -940,10 +963,11 @@ extern "C" int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, cons
     KZV_TRY(decode_step_check(m, d_tokens, d_posids, d_valid, d_logits, "decode_step_graph"));
     if (!stream) return kzv_fail(KZV_E_ARG, "decode_step_graph: needs a non-default stream (stream capture)");
     KZV_TRY(ensure_kv_cache(m));
+    KZV_TRY(ensure_cross_layout(m, (hipStream_t)stream));          // before any capture: a plain launch, once per generation
     m->train = false; m->have_fwd = false;
     hipStream_t s = (hipStream_t)stream;
     const int g = m->rt_cur + 1;
-    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[0], (const void*)(intptr_t)(m->npa * 4096 + m->Be)};
+    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[0], (const void*)((intptr_t)m->ckv_dec ^ (intptr_t)(m->npa * 4096 + m->Be))};
     bool same = m->dgraph[g] != nullptr && m->dg_ld[g] == ld_valid;
     for (int i = 0; i < 6 && same; ++i) same = m->dg_key[g][i] == key[i];
     if (!same) {                               // (re)capture: the step with its index read from m->d_t, then t += 1

@@ -294,7 +294,9 @@ class TrOCRModel:
         self.training = False
         nb = max(1, int(num_beams))
         BB = B * nb
-        share = use_cache and nb > 1          # beams share their image's encoder states / cross-attention K/V (kzv_encode_images)
+        # cached decoding runs the encoder and the cross-attention K/V once per IMAGE (kzv_encode_images): beams share them, and no
+        # teacher-forced decoder pass is spent on the BOS-only prompt
+        share = use_cache
         if nb > 1 and not share:
             px = px.repeat_interleave(nb, dim=0)
         ids0 = torch.full((BB, Lh), c.pad_id, dtype=torch.int64, device=self.device)
