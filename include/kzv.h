@@ -132,9 +132,10 @@ int kzv_beam_topk(const float* d_logits, int64_t ld, const float* d_beam_scores,
 int kzv_decode_prep(const int64_t* d_ids, int64_t ld_ids, int t, int pad_id, int batch, int64_t* d_tokens, uint8_t* d_valid, int64_t ld_valid,
                     int32_t* d_posids, void* stream);
 /* Greedy token selection (num_beams = 1): d_ids[:, t + 1] = argmax of the row (first maximum), or pad_id once the sequence has
- * emitted eos_id (d_done [batch] is read and updated); d_flags[0] = sequences still running after this step. */
+ * emitted eos_id (d_done [batch] is read and updated); d_running[t] += sequences still running after this step (the caller
+ * zeroes d_running [>= t + 1 ints] once per generation and may read it every few steps: steps past the end only write padding). */
 int kzv_greedy_update(const float* d_logits, int64_t ld, int vocab, int64_t* d_ids, int64_t ld_ids, int t, uint8_t* d_done, int batch,
-                      int pad_id, int eos_id, int32_t* d_flags, void* stream);
+                      int pad_id, int eos_id, int32_t* d_running, void* stream);
 /* One beam-search step's bookkeeping on the device -- what transformers' GenerationMixin._beam_search does between two decoder
  * steps (running beams of the next step, finished list, early-stop heuristic; kzv/beam.py states it in torch ops and is pinned
  * against HF on the CPU).  State arrays live in caller memory for the whole generation; token rows are double-buffered (the

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restr
         ids[(int64_t)b * ld_ids + t + 1] = nxt;
         const bool now = was || nxt == eos;
         done[b] = now ? 1 : 0;
-        if (!now) atomicAdd(flags, 1);
+        if (!now) atomicAdd(flags + t, 1);
     }
 }
 
@@ -561,7 +561,6 @@ extern "C" int kzv_greedy_update(const float* d_logits, int64_t ld, int vocab, i
                                  int pad_id, int eos_id, int32_t* d_flags, void* stream) {
     if (!d_logits || !d_ids || !d_done || !d_flags || batch < 1 || vocab < 1 || ld < vocab || t < 0 || t + 1 >= ld_ids) return kzv_fail(KZV_E_ARG, "greedy_update: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(d_flags, 0, sizeof(int), s) != hipSuccess) return kzv_fail(KZV_E_HIP, "greedy_update: memset");
     hipLaunchKernelGGL(greedy_update_kernel, dim3(batch), dim3(256), 0, s, d_logits, ld, vocab, d_ids, ld_ids, t, d_done, pad_id, eos_id, d_flags);
     return kzv_check_launch("greedy_update");
 }

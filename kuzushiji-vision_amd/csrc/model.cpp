@@ -925,6 +925,8 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
         x = a.x3; xh = a.x3h;
     }
     KZV_TRY(gemm_ln(m, xh, Hd, m->w_hd, B, Hd, P + m->hd_b, nullptr, true, m->hd_gelu, m->hd_pre, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, s));
+    if (m->V % 4 == 0)        // straight into the caller's [B, V] buffer (the padded scratch + copy costs a launch per token)
+        return gemm(m->hd_ln, Hd, m->w_word, false, B, m->V, Hd, m->V, P + m->hbias, d_logits, m->V, KZV_EPI_F32, s);
     KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, B, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
     KZV_TRY(kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s));
     return KZV_OK;

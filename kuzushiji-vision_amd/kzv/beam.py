@@ -31,19 +31,23 @@ NEG = -1.0e9
 
 def greedy(step, batch: int, max_len: int, pad_id: int, bos_id: int, eos_id: int, device, update=None):
     """``num_beams=1``: argmax per step; finished rows emit padding; stops when every row has emitted EOS.
-    ``update(logits, ids, t, done) -> flags`` (optional, kzv_greedy_update): the selection in one launch; flags[0] = rows running."""
+    ``update(logits, ids, t, done) -> running`` (optional, kzv_greedy_update): the selection in one launch; running[t] = rows
+    still running after step t."""
     import torch
     ids = torch.full((batch, max_len), pad_id, dtype=torch.int64, device=device)
     ids[:, 0] = bos_id
     if update is not None:
+        # the stop test costs a host round trip: taken every 4th step; the steps run past the end only write padding, and the
+        # per-step counters say where the end was
         done8 = torch.zeros(batch, dtype=torch.uint8, device=device)
-        n = 1
+        running = None
         for t in range(max_len - 1):
-            flags = update(step(t, ids), ids, t, done8)
-            n = t + 2
-            if int(flags[0]) == 0:                                  # the one host synchronisation of the step
-                break
-        return ids[:, :n]
+            running = update(step(t, ids), ids, t, done8)
+            if t % 4 == 3 or t == max_len - 2:
+                r = running[:t + 1].tolist()
+                if 0 in r:
+                    return ids[:, :r.index(0) + 2]
+        return ids[:, :max_len]
     done = torch.zeros(batch, dtype=torch.bool, device=device)
     n = 1
     for t in range(max_len - 1):
@@ -199,12 +203,12 @@ def make_device_hooks(batch, num_beams, max_len, vocab, eos_id, early_stopping, 
     return topk, update
 
 
-def make_greedy_hook(batch, vocab, pad_id, eos_id, device):
+def make_greedy_hook(batch, vocab, pad_id, eos_id, device, max_len=4096):
     """``update`` for greedy() on the GPU (kzv_greedy_update through the C ABI, current stream)."""
     import torch
     from . import _lib as L
     lib = L.load()
-    flags = torch.empty(1, dtype=torch.int32, device=device)
+    flags = torch.zeros(max(2, int(max_len)), dtype=torch.int32, device=device)     # sequences still running after step t
 
     def update(logits, ids, t, done8):
         L.check(lib.kzv_greedy_update(logits.data_ptr(), logits.stride(0), vocab, ids.data_ptr(), ids.stride(0), t, done8.data_ptr(), batch,

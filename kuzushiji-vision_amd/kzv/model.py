@@ -357,7 +357,7 @@ class TrOCRModel:
                     L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")
                     L.check(lib.kzv_decode_begin(self._h, L.stream_handle()), "decode_begin")
                 if nb == 1:
-                    gupd = BM.make_greedy_hook(B, c.vocab, c.pad_id, c.eos_id, self.device) if self.device.type == "cuda" and os.environ.get("KZV_BEAM_TOPK", "1") != "0" else None
+                    gupd = BM.make_greedy_hook(B, c.vocab, c.pad_id, c.eos_id, self.device, Lh) if self.device.type == "cuda" and os.environ.get("KZV_BEAM_TOPK", "1") != "0" else None
                     out = BM.greedy(step, B, Lh, c.pad_id, c.bos_id, c.eos_id, self.device, update=gupd)
                 else:
                     out = BM.beam_search(step, reorder, B, nb, Lh, c.vocab, c.pad_id, c.bos_id, c.eos_id, self.device,

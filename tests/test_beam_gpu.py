@@ -48,7 +48,7 @@ def test_fused_beam_search_equals_the_torch_statement(B, nb, V, T, eos_bias, ear
 @pytest.mark.parametrize("B,V,T,eos_bias", [(5, 41, 12, 2.0), (256, 4300, 20, 5.0), (3, 157, 9, -5.0)])
 def test_fused_greedy_equals_the_torch_statement(B, V, T, eos_bias):
     want = BM.greedy(_step_fn(V, T, B + V, eos_bias), B, T, PAD, BOS, EOS, DEV)
-    got = BM.greedy(_step_fn(V, T, B + V, eos_bias), B, T, PAD, BOS, EOS, DEV, update=BM.make_greedy_hook(B, V, PAD, EOS, DEV))
+    got = BM.greedy(_step_fn(V, T, B + V, eos_bias), B, T, PAD, BOS, EOS, DEV, update=BM.make_greedy_hook(B, V, PAD, EOS, DEV, T))
     torch.cuda.synchronize()
     assert torch.equal(got.cpu(), want.cpu())
     # first maximum on exact ties, like torch.argmax
@@ -56,6 +56,6 @@ def test_fused_greedy_equals_the_torch_statement(B, V, T, eos_bias):
     ids = torch.full((B, T), PAD, dtype=torch.int64, device=DEV)
     done = torch.zeros(B, dtype=torch.uint8, device=DEV)
     flat[:, 7] = 1.0; flat[:, 19] = 1.0
-    BM.make_greedy_hook(B, V, PAD, EOS, DEV)(flat, ids, 0, done)
+    BM.make_greedy_hook(B, V, PAD, EOS, DEV, T)(flat, ids, 0, done)
     torch.cuda.synchronize()
     assert ids[:, 1].tolist() == [7] * B
