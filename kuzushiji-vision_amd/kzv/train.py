@@ -53,7 +53,9 @@ def parse_args(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--devices", type=str, default=None, help="ocr_lightning spelling of --gpus")
     p.add_argument("--accelerator", type=str, default="gpu")
-    p.add_argument("--precision", type=str, default="bf16-mixed", choices=["16-mixed", "32", "bf16-mixed"])
+    p.add_argument("--precision", type=str, default="bf16-mixed", choices=["16-mixed", "32", "bf16-mixed", "fp8-mixed"],
+                   help="bf16-mixed = the reference's setting and this engine's arithmetic; fp8-mixed (an extension, BASELINE configs[4]) "
+                        "additionally runs the encoder's QKV / fc1 / fc2 forward GEMMs on e4m3 operands (hidden and ffn sizes must be multiples of 256)")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--device_preprocess", action="store_true",
                    help="resize / pad / normalise the decoded crops on the GPU (kzv.preprocess; byte-exact with the PIL transform)")
@@ -74,8 +76,8 @@ def main(argv=None):
         args.gpus = int(args.devices) if str(args.devices).isdigit() else len(str(args.devices).split(","))
     if args.accelerator != "gpu" or args.gpus < 1:
         raise SystemExit("this engine runs on MI355X GPUs only (the reference CPU Trainer branch is not provided)")
-    if args.precision != "bf16-mixed":
-        raise SystemExit("the engine implements bf16-mixed (scripts/train_trocr.py:68 default) only")
+    if args.precision not in ("bf16-mixed", "fp8-mixed"):
+        raise SystemExit("the engine implements bf16-mixed (scripts/train_trocr.py:68 default) and its fp8-mixed extension only")
     hd = args.encoder_hidden_size / max(1, args.encoder_num_heads)
     if hd != int(hd) or int(hd) % 8 or hd > 128:
         raise SystemExit(f"encoder head_dim {hd:g} is not supported: --encoder_hidden_size / --encoder_num_heads must be a multiple of 8 up to 128")
@@ -99,7 +101,8 @@ def main(argv=None):
                       "num_attention_heads": args.encoder_num_heads, "intermediate_size": args.encoder_hidden_size * 4,
                       "hidden_dropout_prob": 0.1, "attention_probs_dropout_prob": 0.1}   # :111-121
     model = TrOCRModel(encoder_config, decoder_path, learning_rate=args.learning_rate, beta1=args.beta1, beta2=args.beta2,
-                       epsilon=args.epsilon, weight_decay=args.weight_decay, device=f"cuda:{local}", init_seed=args.seed)
+                       epsilon=args.epsilon, weight_decay=args.weight_decay, device=f"cuda:{local}", init_seed=args.seed,
+                       fp8=args.precision == "fp8-mixed")
     model._step_seed = 1_000_003 * rank
     if args.synthetic:
         n_val = max(args.batch_size, args.synthetic // 10)

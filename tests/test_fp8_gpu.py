@@ -237,3 +237,36 @@ def test_fp8_path_stays_close_to_the_bf16_path(tmp_path):
     assert np.sqrt(np.mean((a - b) ** 2)) < 0.02 * span
     assert abs(outs[False][1] - outs[True][1]) < 0.02 * abs(outs[False][1])
     assert (a.argmax(-1) == b.argmax(-1)).mean() > 0.9
+
+
+def test_fp8_through_the_cli_with_width_buckets_and_generation(tmp_path):
+    """`python -m kzv.train --precision fp8-mixed`: a short synthetic run (train, validate with beam-4 decoding, checkpoint, test
+    phase), and the fp8 switch together with width buckets (per-batch encoder length) against the oracle's recipe per bucket."""
+    from kzv.train import main
+    hist = main(["--synthetic", "16", "--batch_size", "4", "--image_size", "128", "32", "--encoder_hidden_size", "256", "--encoder_num_layers", "2",
+                 "--encoder_num_heads", "4", "--max_epochs", "1", "--max_length", "24", "--precision", "fp8-mixed", "--output_dir", str(tmp_path),
+                 "--experiment_name", "f8"])
+    assert hist and all(np.isfinite(v) for _, v in hist)
+    assert main.test_metrics is not None and np.isfinite(main.test_metrics["test_loss"])
+    cfg = _no_dropout(_f8_config())
+    d = build_decoder_dir(str(tmp_path / "dec"), cfg)
+    m = TrOCRModel(cfg.encoder_config_dict(), d, init_seed=4, load_tokenizer=False, fp8=True, width_buckets=(64, 96, 128))
+    m.trim_padding = False
+    m.train()
+    sd = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 4))
+    for w in (64, 128, 96):
+        px, lab = synthetic_batch(cfg, 3, 20, seed=w, min_chars=3, max_chars=15)
+        px = px[:, :, :, :w].copy()
+        loss, logits = m.forward_loss(torch.from_numpy(px), torch.from_numpy(lab), want_logits=True, seed=1)
+        torch.cuda.synchronize()
+        used = m.fp8_act_scales().tolist()
+        # the oracle at this width: a model of that image size whose position table holds the rows of the same (h, w) cells
+        cw = dataclasses.replace(cfg, image_w=w)
+        gh, gw, gmax = cfg.image_h // cfg.patch_h, w // cfg.patch_w, cfg.image_w // cfg.patch_w
+        sdw = dict(sd)
+        pos = sd["encoder.position_embeddings"]
+        rows = [0] + [1 + r * gmax + c for r in range(gh) for c in range(gw)]
+        sdw["encoder.position_embeddings"] = pos[:, rows, :]
+        r = O.forward_backward(cw, sdw, px, lab, fp8={"act_qscale": used})
+        span = np.abs(r["logits"]).max()
+        assert np.abs(logits.cpu().numpy() - r["logits"]).max() < 1.5e-2 * span, w
