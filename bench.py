@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--dec-layers", type=int, default=6, help="6 = BASELINE.json configs[1]; 12 = reference decoder")
     ap.add_argument("--encoder", choices=["vit_b", "vit_l"], default="vit_b",
                     help="vit_b = the benchmark (configs[1]/[2]); vit_l = configs[3]'s ViT-L/16 encoder (a side measurement)")
+    ap.add_argument("--fp8-mode", type=int, default=2, choices=[1, 2], help="with --fp8: 1 = forward GEMMs only, 2 = + the MLP's input-gradient GEMMs")
     ap.add_argument("--fp8", action="store_true",
                     help="side measurement (configs[4], second half): the encoder's QKV / fc1 / fc2 forward GEMMs on e4m3 operands; "
                          "NOT the benchmark line, which is bf16")
@@ -151,7 +152,7 @@ def main():
 
     with tempfile.TemporaryDirectory() as tmp:
         d = build_decoder_dir(os.path.join(tmp, "dec"), cfg)
-        model = TrOCRModel(cfg.encoder_config_dict(), d, device=dev, init_seed=42, load_tokenizer=False, fp8=args.fp8)
+        model = TrOCRModel(cfg.encoder_config_dict(), d, device=dev, init_seed=42, load_tokenizer=False, fp8=args.fp8_mode if args.fp8 else 0)
     model._step_seed = 1_000_003 * rank            # per-rank dropout streams
     opt = model.configure_optimizers()
     model.train()

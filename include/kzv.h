@@ -224,7 +224,7 @@ int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream);
 int kzv_set_rows_max_m(int n);
 
 /* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path on CDNA4"; beyond the reference, which has no fp8) ----
- * C[M,N] = (A8[M,K] . B8[N,K]^T) * a_scale[m] * b_scale[n] (+bias) with the BF16 / GELU / RESID epilogue of kzv_gemm_nt.
+ * C[M,N] = (A8[M,K] . B8[N,K]^T) * a_scale[m] * b_scale[n] (+bias) with the BF16 / GELU / RESID / DGELU epilogue of kzv_gemm_nt.
  * A8, B8: OCP e4m3 bytes; row m of A8 holds A[m,:] / a_scale[m] (likewise B8 / b_scale).  fp32 accumulate on the block-scaled
  * MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): twice the bf16 MFMA rate.  K % 256 == 0.
  * GELU only: when c8 is set, a second copy of C as e4m3, quantised with the per-tensor multiplier *c8_qscale (device scalar),
@@ -242,6 +242,7 @@ typedef struct kzv_gemm_nt_fp8_args {
     const float* c8_qscale; float* c8_amax;
     int32_t M, N, K, n_valid;
     float drop_p; uint32_t drop_key;  /* RESID dropout on (acc*scales+bias) */
+    const float* c8_rowq;             /* DGELU: fp32 [M], c8[m,:] = e4m3(C[m,:] * c8_rowq[m]) (required with DGELU) */
 } kzv_gemm_nt_fp8_args;
 int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void* stream);
 /* q[r,:] = e4m3(x[r,:] * 448 / amax_r), scale[r] = amax_r / 448 (1 for an all-zero row); cols % 4 == 0.  The quantiser of the
@@ -252,7 +253,9 @@ int kzv_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta,
                           float* stats, int rows, int H, float eps, void* stream);
 /* Model switch (call before kzv_model_bind; encoder hidden and ffn must be multiples of 256): 1 = the encoder's QKV, fc1 and fc2
  * forward GEMMs run on e4m3 operands (weights quantised per output row at kzv_model_sync_weights; LayerNorm outputs per token
- * row; GELU outputs per tensor with the previous forward's amax); everything else, backward included, stays bf16. */
+ * row; GELU outputs per tensor with the previous forward's amax); 2 = also the MLP's two input-gradient GEMMs (transposed e4m3
+ * weights; gradient rows quantised by their amax in the LayerNorm backward, and per row by a norm bound in the DGELU epilogue).
+ * Everything else -- weight gradients, attention, the decoder -- stays bf16. */
 int kzv_set_fp8(kzv_model* m, int mode);
 int kzv_get_fp8(const kzv_model* m);
 /* Parity hook: the per-tensor multipliers the last forward quantised each encoder layer's GELU output with -> d_out[enc_layers]. */

@@ -309,19 +309,30 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const KzvQuantDesc* __r
         d = desc[lo];
     }
     const int r = grow - d.row0;
-    const float4* x = (const float4*)(d.src + (int64_t)r * d.cols);
     const int nc = d.cols >> 2;                       // cols % 4 == 0 is checked on the host
-    float amax = 0.f;
+    const float4* x = d.src ? (const float4*)(d.src + (int64_t)r * d.cols) : nullptr;
+    const uint2* x16 = d.src ? nullptr : (const uint2*)(d.src16 + (int64_t)r * d.ld16);
+    auto at = [&](int i) {
+        if (x) return x[i];
+        const uint2 u = x16[i];
+        return make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
+    };
+    float amax = 0.f, ssq = 0.f;
     for (int i = lane; i < nc; i += 64) {
-        const float4 v = x[i];
+        const float4 v = at(i);
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        ssq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     amax = wave_max(amax);
     const float qs = amax > 0.f ? KZV_FP8_MAX / amax : 1.f;
+    if (d.normmax) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) atomicMax((unsigned*)d.normmax, __float_as_uint(sqrtf(ssq)));     // floats >= 0 order as integers
+    }
     if (lane == 0) d.scale[r] = amax > 0.f ? amax / KZV_FP8_MAX : 1.f;
     unsigned* q = (unsigned*)(d.dst + (int64_t)r * d.cols);
     for (int i = lane; i < nc; i += 64) {
-        const float4 v = x[i];                        // second read of a row this wave just streamed: L2 / L1 hit
+        const float4 v = at(i);                       // second read of a row this wave just streamed: L2 / L1 hit
         q[i] = pack_fp8x4(v.x * qs, v.y * qs, v.z * qs, v.w * qs);
     }
 }
@@ -441,7 +452,7 @@ int kzv_quant_rows(const KzvQuantDesc* d_desc, int ndesc, int total_rows, hipStr
 extern "C" int kzv_quant_rows_fp8(const float* x, int64_t rows, int64_t cols, void* q, float* scale, void* stream) {
     if (!x || !q || !scale || rows <= 0 || cols <= 0 || rows > 0x7fffffff) return kzv_fail(KZV_E_ARG, "quant_rows_fp8: null/empty");
     if (cols % 4 || ((uintptr_t)x & 15) || ((uintptr_t)q & 3)) return kzv_fail(KZV_E_ARG, "quant_rows_fp8: cols must be a multiple of 4, x 16-byte aligned");
-    const KzvQuantDesc one{x, (unsigned char*)q, scale, (int)rows, (int)cols, 0};
+    const KzvQuantDesc one{x, (unsigned char*)q, scale, (int)rows, (int)cols, 0, nullptr, 0, nullptr};
     hipLaunchKernelGGL(quant_rows_kernel, dim3(((int)rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const KzvQuantDesc*)nullptr, 0, one, (int)rows);
     return kzv_check_launch("quant_rows_fp8");
 }

@@ -462,7 +462,10 @@ extern "C" int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void
     if (a->N % 4 || a->ldc % 4) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: N and ldc must be multiples of 4");
     if (a->lda % 16 || a->ldb % 16) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: lda/ldb must be multiples of 16 (16-byte rows)");
     if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: operands must be 16-byte aligned");
-    if (epilogue != KZV_EPI_BF16 && epilogue != KZV_EPI_GELU && epilogue != KZV_EPI_RESID) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: epilogue must be BF16, GELU or RESID");
+    if (epilogue != KZV_EPI_BF16 && epilogue != KZV_EPI_GELU && epilogue != KZV_EPI_RESID && epilogue != KZV_EPI_DGELU)
+        return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: epilogue must be BF16, GELU, RESID or DGELU");
+    if (epilogue == KZV_EPI_DGELU && (!a->aux || a->ldaux % 4 || !a->c8 || !a->c8_rowq || a->ldc8 % 4))
+        return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: DGELU needs aux, c8 and c8_rowq");
     if (epilogue == KZV_EPI_RESID && (!a->resid || a->ldr % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: RESID needs resid, ldr%4==0");
     if (epilogue == KZV_EPI_GELU && (!a->aux || a->ldaux % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: GELU needs aux");
     if (epilogue == KZV_EPI_GELU && a->c8 && (!a->c8_qscale || !a->c8_amax || a->ldc8 % 4)) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: c8 needs c8_qscale, c8_amax, ldc8%4==0");
@@ -475,7 +478,7 @@ extern "C" int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void
     p.drop_key = a->drop_key;
     p.strip = kzv_nt_strip();
     p.a_scale = a->a_scale; p.b_scale = a->b_scale;
-    p.c8 = (unsigned char*)a->c8; p.ldc8 = a->ldc8; p.c8_qscale = a->c8_qscale; p.c8_amax = a->c8_amax;
+    p.c8 = (unsigned char*)a->c8; p.ldc8 = a->ldc8; p.c8_qscale = a->c8_qscale; p.c8_amax = a->c8_amax; p.c8_rowq = a->c8_rowq;
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(4, 2.0 * a->M * p.n_valid * a->K, s);
     const int rc = kzv_nt256p_fp8_launch(p, epilogue, s);

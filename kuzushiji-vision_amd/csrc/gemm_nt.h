@@ -17,6 +17,8 @@ struct NtParams {
     // GELU epilogue of the fp8 kernel: a second copy of C as e4m3 (the next GEMM's A operand), quantised with the
     // per-tensor multiplier *c8_qscale; the largest |C| seen is folded into *c8_amax (next step's multiplier)
     unsigned char* c8; int64_t ldc8; const float* c8_qscale; float* c8_amax;
+    // DGELU epilogue of the fp8 kernel: the e4m3 copy is quantised per ROW with the multipliers c8_rowq[m] (no amax tracking)
+    const float* c8_rowq;
 };
 
 // One thread finishes 4 consecutive columns n0..n0+3 of output row m: v = accumulator + bias on entry;
@@ -89,7 +91,7 @@ int kzv_nt_strip();      // KZV_NT_STRIP (default 3)
 int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);
 // gemm_nt256p.hip (persistent variant of the same schedule): same contract.
 int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s);
-// fp8 (e4m3) operands on the block-scaled MFMA, same persistent schedule (gemm_nt256p.hip); epilogues BF16, GELU, RESID.
+// fp8 (e4m3) operands on the block-scaled MFMA, same persistent schedule (gemm_nt256p.hip); epilogues BF16, GELU, RESID, DGELU.
 // Returns KZV_OK or an error: there is no other fp8 kernel to fall back to.
 int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s);
 // gemm_rows.hip (few rows: one wave per 16x64 tile, operands straight from L2): same contract.  Taken inside a KzvRowsScope

@@ -65,7 +65,7 @@ constexpr int cmin(int a, int b) { return a < b ? a : b; }
 // VMEM operations one wave issues while draining an interior tile (32 four-column groups per lane)
 template <int EPI, bool F8> constexpr int drain_ops() {
     // GELU*: two stores; RESID/DGELU: load + store; fp8: + the row scale (and the e4m3 copy of a GELU output)
-    return ((EPI == KZV_EPI_BF16 || EPI == KZV_EPI_F32) ? 32 : 64) + (F8 ? (EPI == KZV_EPI_GELU ? 64 : 32) : 0);
+    return ((EPI == KZV_EPI_BF16 || EPI == KZV_EPI_F32) ? 32 : 64) + (F8 ? ((EPI == KZV_EPI_GELU || EPI == KZV_EPI_DGELU) ? 64 : 32) : 0);
 }
 
 struct TileSrc {            // where the next half-tiles of one half index (h) come from
@@ -255,11 +255,11 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
             }
             if (EPI == KZV_EPI_GELU && p.c8) qs = *p.c8_qscale;
         }
-        auto emit8 = [&](int m, const float (&y)[4]) {        // e4m3 copy of a finished GELU row group (plain stores: L2 merges the 64-B pieces)
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
-            *(unsigned*)(p.c8 + (int64_t)m * p.ldc8 + n0) = pack_fp8x4(y[0] * qs, y[1] * qs, y[2] * qs, y[3] * qs);
+        auto emit8 = [&](int m, const float (&y)[4], float q) {   // e4m3 copy of a finished row group (plain stores: L2 merges the 64-B pieces)
+            if (EPI == KZV_EPI_GELU) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+            *(unsigned*)(p.c8 + (int64_t)m * p.ldc8 + n0) = pack_fp8x4(y[0] * q, y[1] * q, y[2] * q, y[3] * q);
         };
-        auto block_loads = [&](int i, float4 (&r4)[4], uint2 (&u2)[4], float (&sa)[4]) {
+        auto block_loads = [&](int i, float4 (&r4)[4], uint2 (&u2)[4], float (&sa)[4], float (&rq)[4]) {
             const int m0 = tm * 256 + wr * 128 + i * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -267,15 +267,16 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
                 if (EPI == KZV_EPI_RESID) r4[q] = *(const float4*)(p.resid + (int64_t)m * p.ldr + n0);
                 if (EPI == KZV_EPI_DGELU) u2[q] = *(const uint2*)(p.aux + (int64_t)m * p.ldaux + n0);
                 if (F8) sa[q] = p.a_scale[m];
+                if (F8 && EPI == KZV_EPI_DGELU) rq[q] = p.c8_rowq[m];      // (the launcher insists on c8 + c8_rowq for DGELU)
             }
         };
         // interior tiles: branch-free (counted vmcnt; see gemm_nt256.hip), the residual / pre-activation loads running
         // LOOK row blocks ahead of their use; edge tiles: guarded, row by row
-        constexpr int LOOK = (F8 && EPI == KZV_EPI_RESID) ? 3 : 4;     // fp8 + residual: one block less in flight (the row scales need registers too)
-        float4 r4[8][4]; uint2 u2[8][4]; float sa[8][4];
+        constexpr int LOOK = (F8 && (EPI == KZV_EPI_RESID || EPI == KZV_EPI_DGELU)) ? 3 : 4;     // fp8 + residual: one block less in flight (the row scales need registers too)
+        float4 r4[8][4]; uint2 u2[8][4]; float sa[8][4], rq[8][4];
         if constexpr (interior) {
 #pragma unroll
-            for (int i = 0; i < LOOK; ++i) block_loads(i, r4[i], u2[i], sa[i]);
+            for (int i = 0; i < LOOK; ++i) block_loads(i, r4[i], u2[i], sa[i], rq[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                         // accumulator row block i: tile rows wr*128 + i*16 .. +15
@@ -294,9 +295,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = F8 ? fmaf(a4[r], sa[i][q] * sw4[r], b4[r]) : a4[r] + b4[r];
                     nt_emit<EPI>(p, m0 + row, n0, v, r4[i][q], u2[i][q]);
-                    if constexpr (F8 && EPI == KZV_EPI_GELU) { if (p.c8) emit8(m0 + row, v); }
+                    if constexpr (F8 && EPI == KZV_EPI_GELU) { if (p.c8) emit8(m0 + row, v, qs); }
+                    if constexpr (F8 && EPI == KZV_EPI_DGELU) emit8(m0 + row, v, rq[i][q]);
                 }
-                if (i + LOOK < 8) block_loads(i + LOOK, r4[i + LOOK], u2[i + LOOK], sa[i + LOOK]);
+                if (i + LOOK < 8) block_loads(i + LOOK, r4[i + LOOK], u2[i + LOOK], sa[i + LOOK], rq[i + LOOK]);
             } else {
 #pragma unroll 1
                 for (int q = 0; q < 4; ++q) {
@@ -312,7 +314,8 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = nv[r] ? (F8 ? fmaf(a4[r], sr * sw4[r], b4[r]) : a4[r] + b4[r]) : 0.f;
                         nt_emit<EPI>(p, m, n0, v, e4, eu);
-                        if constexpr (F8 && EPI == KZV_EPI_GELU) { if (p.c8) emit8(m, v); }
+                        if constexpr (F8 && EPI == KZV_EPI_GELU) { if (p.c8) emit8(m, v, qs); }
+                        if constexpr (F8 && EPI == KZV_EPI_DGELU) emit8(m, v, p.c8_rowq[m]);
                     }
                 }
             }
@@ -437,8 +440,8 @@ int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt256p_kernel<E, true>), dim3(grid), dim3(512), LDS_BYTES, s, p, tiles, tilesN, kzv_nt_strip());   \
     } break;
     switch (epilogue) {
-        KZV_NT256P8_CASE(KZV_EPI_BF16) KZV_NT256P8_CASE(KZV_EPI_GELU) KZV_NT256P8_CASE(KZV_EPI_RESID)
-        default: return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: epilogue must be BF16, GELU or RESID");
+        KZV_NT256P8_CASE(KZV_EPI_BF16) KZV_NT256P8_CASE(KZV_EPI_GELU) KZV_NT256P8_CASE(KZV_EPI_RESID) KZV_NT256P8_CASE(KZV_EPI_DGELU)
+        default: return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: epilogue must be BF16, GELU, RESID or DGELU");
     }
 #undef KZV_NT256P8_CASE
     return KZV_OK;

@@ -8,10 +8,13 @@
 int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* stats,
                   int rows, int H, float eps, int seq, int drop_first, float drop_p, uint32_t drop_key, hipStream_t s,
                   void* y8 = nullptr, float* y8_scale = nullptr);    // y8: e4m3 copy with one scale per row (fp8 path)
+// fp8 input-gradient path: e4m3 copy of the masked dx rows (per-row amax scale) + the per-row quantisation multiplier (and its
+// inverse) of the gradient tensor computed from them next, bounded through *wnorm = the largest row norm of that GEMM's weight
+struct KzvLnBwdF8 { void* out8; float* scale; float* rq; float* rqinv; const float* wnorm; };
 int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
                   int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
                   float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16 = nullptr, float out_drop_p = 0.f,
-                  uint32_t out_drop_key = 0);
+                  uint32_t out_drop_key = 0, const KzvLnBwdF8* f8 = nullptr);
 
 // elementwise.hip
 int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s);
@@ -39,7 +42,11 @@ struct KzvCastDesc {         // one 2-D fp32 weight -> bf16 copy (+ optional tra
 int kzv_cast_weights(const KzvCastDesc* d_desc, int ndesc, int total_tiles, hipStream_t s);
 
 // fp8 path: fp32 rows -> e4m3 rows quantised by their own largest |x| (dst ~ x * 448 / amax, scale = amax / 448)
-struct KzvQuantDesc { const float* src; unsigned char* dst; float* scale; int rows, cols, row0; };
+struct KzvQuantDesc {
+    const float* src; unsigned char* dst; float* scale; int rows, cols, row0;
+    const bf16_t* src16; int64_t ld16;      // src == nullptr: bf16 rows with stride ld16 (the transposed weight copies)
+    float* normmax;                         // optional: *normmax = max(*normmax, ||row||_2) (atomic; reset by the caller)
+};
 int kzv_quant_rows(const KzvQuantDesc* d_desc, int ndesc, int total_rows, hipStream_t s);
 // fp8 path, once per forward: next multiplier of every per-tensor activation site from the largest |value| the last
 // forward saw (power of two, one binade of headroom; unchanged while amax == 0), amax reset, and the dequantisation

@@ -100,7 +100,12 @@ struct LnBwd {
     unsigned thr16; float inv_keep; unsigned key;
     bf16_t* out16; unsigned o_thr16; float o_inv_keep; unsigned o_key;   // optional: bf16 copy of the TOTAL dx, dropout-masked
     float* partial;                      // [LN_SLOTS][2][H] gamma/beta partial sums (zero on entry, zeroed again by the reduce kernel)
+    // fp8 input-gradient path (fast kernel only): beside out16, an e4m3 copy of the masked dx row quantised by its own amax
+    // (out8 ~ row / out8_scale[row]) and the multiplier the NEXT gradient tensor of this row will be quantised with, from the
+    // bound |dy . w| <= ||dy|| ||w||: out8_rq[row] = 448 / (KZV_F8_BOUND ||row||_2 *rq_wnorm), out8_rqinv = its inverse
+    unsigned char* out8; float* out8_scale; float* out8_rq; float* out8_rqinv; const float* rq_wnorm;
 };
+#define KZV_F8_BOUND 1.4125f             // max gelu' (1.13) x 1.25 for what e4m3 rounding adds to the two norms
 
 constexpr int LN_SLOTS = 32;
 
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
 // Pipelined variant for H = NC*256 exactly (no lane guards), dy type and accumulate mode fixed at compile time: the
 // row loop is straight-line, so hipcc counts its vmcnt waits, and the loads of row r+1 are in flight while row r is
 // reduced and stored (two rows of latency overlap per wave instead of one).
-template <int NC, bool DYF32, bool ACC>
+template <int NC, bool DYF32, bool ACC, bool F8>
 __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const LnBwd p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 waves][2][H] floats
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -270,6 +275,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const LnBwd p) {
         }
         const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
         float4* dxr = (float4*)(p.dx + (int64_t)row * p.H);
+        float4 om[F8 ? NC : 1];
+        float amax = 0.f, ssq = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int i = lane + c * 64;
@@ -285,7 +292,26 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const LnBwd p) {
                     o.z *= drop_keep(b1, 0, p.o_thr16, p.o_inv_keep); o.w *= drop_keep(b1, 1, p.o_thr16, p.o_inv_keep);
                 }
                 ((uint2*)(p.out16 + (int64_t)row * p.H))[i] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+                if (F8) {
+                    om[c] = o;
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                    ssq += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                }
             }
+        }
+        if (F8) {
+            amax = wave_max(amax);
+            ssq = wave_sum(ssq);
+            const float qs = amax > 0.f ? KZV_FP8_MAX / amax : 1.f;
+            if (lane == 0) {
+                p.out8_scale[row] = amax > 0.f ? amax / KZV_FP8_MAX : 1.f;
+                const float bound = KZV_F8_BOUND * sqrtf(ssq) * *p.rq_wnorm;
+                const float rq = bound > 0.f ? KZV_FP8_MAX / bound : 1.f;
+                p.out8_rq[row] = rq; p.out8_rqinv[row] = 1.f / rq;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                ((unsigned*)(p.out8 + (int64_t)row * p.H))[lane + c * 64] = pack_fp8x4(om[c].x * qs, om[c].y * qs, om[c].z * qs, om[c].w * qs);
         }
     };
     if (n > 0) {
@@ -362,11 +388,16 @@ int kzv_ln_fwd_ex(const float* x, const float* gamma, const float* beta, void* y
 
 int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* stats, const float* gamma, float* dx,
                   int accumulate_dx, float* dgamma, float* dbeta, int rows, int H, int seq, int drop_first,
-                  float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16, float out_drop_p, uint32_t out_drop_key) {
+                  float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16, float out_drop_p, uint32_t out_drop_key, const KzvLnBwdF8* f8) {
     if (!dy || !x || !stats || !gamma || !dx || !dgamma || !dbeta || rows <= 0) return kzv_fail(KZV_E_ARG, "layernorm_bwd: null/empty");
     if (H % 4 || H > MAXC * 256) return kzv_fail(KZV_E_ARG, "layernorm: H must be a multiple of 4 and <= 2048");
     LnBwd p{dy, x, stats, gamma, dx, dgamma, dbeta, rows, H, seq > 0 ? seq : 1, drop_first, dy_is_f32, accumulate_dx, 0, 1.f, drop_key,
-            out16, 0, 1.f, out_drop_key, nullptr};
+            out16, 0, 1.f, out_drop_key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (f8) {
+        if (!out16 || !f8->out8 || !f8->scale || !f8->rq || !f8->rqinv || !f8->wnorm) return kzv_fail(KZV_E_ARG, "layernorm_bwd: the fp8 copy needs out16 and all of its arrays");
+        if (H % 256 || H > 1024) return kzv_fail(KZV_E_ARG, "layernorm_bwd: the fp8 copy needs H = 256, 512, 768 or 1024");
+        p.out8 = (unsigned char*)f8->out8; p.out8_scale = f8->scale; p.out8_rq = f8->rq; p.out8_rqinv = f8->rqinv; p.rq_wnorm = f8->wnorm;
+    }
     kzv_drop_params(drop_p, &p.thr16, &p.inv_keep);
     kzv_drop_params(out_drop_p, &p.o_thr16, &p.o_inv_keep);
     const int ncl = (H / 4 + 63) / 64;
@@ -375,12 +406,13 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     p.partial = ln_partials();
     if (!p.partial) return kzv_fail(KZV_E_HIP, "layernorm_bwd: partial-sum buffer unavailable");
     const bool fast = H == ncl * 256 && ncl <= 4;
+#define KZV_LN_FAST2(NC, A, B)                                                                                 \
+    do { if (f8) hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, A, B, true>), grid, dim3(256), lds, s, p);          \
+         else hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, A, B, false>), grid, dim3(256), lds, s, p); } while (0)
 #define KZV_LN_FAST(NC)                                                                                       \
     do {                                                                                                      \
-        if (dy_is_f32) { if (accumulate_dx) hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, true, true>), grid, dim3(256), lds, s, p);   \
-                         else hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, true, false>), grid, dim3(256), lds, s, p); }              \
-        else { if (accumulate_dx) hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, false, true>), grid, dim3(256), lds, s, p);            \
-               else hipLaunchKernelGGL((ln_bwd_fast_kernel<NC, false, false>), grid, dim3(256), lds, s, p); }                       \
+        if (dy_is_f32) { if (accumulate_dx) KZV_LN_FAST2(NC, true, true); else KZV_LN_FAST2(NC, true, false); }  \
+        else { if (accumulate_dx) KZV_LN_FAST2(NC, false, true); else KZV_LN_FAST2(NC, false, false); }          \
     } while (0)
     if (fast && ncl == 1) KZV_LN_FAST(1);
     else if (fast && ncl == 2) KZV_LN_FAST(2);
@@ -392,6 +424,7 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     else if (ncl == 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), lds, s, p);
 #undef KZV_LN_FAST
+#undef KZV_LN_FAST2
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, s, p.partial, dgamma, dbeta, H);
     return kzv_check_launch("layernorm_bwd");
 }

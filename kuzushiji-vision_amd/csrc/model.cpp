@@ -101,6 +101,13 @@ struct kzv_model {
     unsigned char *x8 = nullptr, *act8 = nullptr;
     float *x8_scale = nullptr, *f8_q = nullptr, *f8_amax = nullptr, *f8_rows = nullptr;
     int64_t f8_stride = 0;
+    // mode 2: also the MLP's two INPUT-GRADIENT GEMMs (d fc2 with the DGELU epilogue, d fc1).  Transposed e4m3 weight copies
+    // (quantised per row from the bf16 transposed copies); the masked gradient rows arriving at fc2 come from the LayerNorm
+    // backward above them as e4m3 with their own amax (dy8, dy8_scale); the gradient of the GELU input is quantised per row
+    // in the DGELU epilogue with a multiplier from the bound ||dy row|| * max ||W2 column|| (rq / rqinv; f8_wnorm[layer]).
+    std::vector<W8> w8t_fc1, w8t_fc2;
+    unsigned char *dy8 = nullptr, *dbig8 = nullptr;
+    float *dy8_scale = nullptr, *dy8_rq = nullptr, *dy8_rqinv = nullptr, *f8_wnorm = nullptr;
     bool side_ok = false;    // mode 2: set only inside the encoder-layer schedule (everything else stays on the caller's stream)
     int side_mode = 0;       // 0 off, 1 free-running wgrads, 2 wgrads only under the HBM-bound kernels (LayerNorm / attention backward)
 };
@@ -184,6 +191,16 @@ W16 take_w(kzv_model* m, Bump& b, int64_t woff, int64_t N, int64_t K, bool need_
     return w;
 }
 
+W8 take_w8t(kzv_model* m, Bump& b, const bf16_t* wt, int64_t ldt, int64_t rows, int64_t cols, float* normmax) {
+    W8 w;
+    w.w = b.take<unsigned char>(rows * cols);
+    w.scale = b.take<float>(rows);
+    KzvQuantDesc d{nullptr, w.w, w.scale, (int)rows, (int)cols, m->qrows, wt, ldt, normmax};
+    m->h_qdesc.push_back(d);
+    m->qrows += (int)rows;
+    return w;
+}
+
 W8 take_w8(kzv_model* m, Bump& b, int64_t woff, int64_t N, int64_t K) {
     W8 w;
     w.w = b.take<unsigned char>(N * K);
@@ -232,6 +249,16 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
             m->w8_qkv[i] = take_w8(m, b, m->ep[i].qkvw, 3 * He, He);
             m->w8_fc1[i] = take_w8(m, b, m->ep[i].fc1w, Fe, He);
             m->w8_fc2[i] = take_w8(m, b, m->ep[i].fc2w, He, Fe);
+        }
+        if (m->fp8 >= 2) {
+            m->f8_wnorm = b.take<float>(m->Le);
+            m->w8t_fc1.resize(m->Le); m->w8t_fc2.resize(m->Le);
+            for (int i = 0; i < m->Le; ++i) {
+                m->w8t_fc2[i] = take_w8t(m, b, m->w_efc2[i].wt, m->w_efc2[i].ldt, Fe, He, m->f8_wnorm ? m->f8_wnorm + i : nullptr);   // rows = W2 columns
+                m->w8t_fc1[i] = take_w8t(m, b, m->w_efc1[i].wt, m->w_efc1[i].ldt, He, Fe, nullptr);
+            }
+            m->dy8 = b.take<unsigned char>(Me * He); m->dbig8 = b.take<unsigned char>(Me * Fe);
+            m->dy8_scale = b.take<float>(Me); m->dy8_rq = b.take<float>(Me); m->dy8_rqinv = b.take<float>(Me);
         }
         m->nqdesc = (int)m->h_qdesc.size();
         m->d_qdesc = b.take<KzvQuantDesc>(m->nqdesc);
@@ -316,12 +343,12 @@ int gemm(const bf16_t* A, int64_t lda, const W16& w, bool transposed, int M, int
 // fp8 forward GEMM of the encoder: A e4m3 with one scale per row, W e4m3 with one scale per output row
 int gemm8(const unsigned char* A, int64_t lda, const float* a_scale, const W8& w, int M, int N, int K, const float* bias, void* C, int64_t ldc,
           int epi, hipStream_t s, const float* resid = nullptr, void* aux = nullptr, int64_t ldaux = 0, float drop_p = 0.f, uint32_t drop_key = 0,
-          unsigned char* c8 = nullptr, const float* c8_qscale = nullptr, float* c8_amax = nullptr) {
+          unsigned char* c8 = nullptr, const float* c8_qscale = nullptr, float* c8_amax = nullptr, const float* c8_rowq = nullptr) {
     kzv_gemm_nt_fp8_args a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.lda = lda; a.a_scale = a_scale; a.B = w.w; a.ldb = K; a.b_scale = w.scale;
     a.C = C; a.ldc = ldc; a.bias = bias; a.resid = resid; a.ldr = ldc; a.aux = aux; a.ldaux = ldaux;
-    a.c8 = c8; a.ldc8 = N; a.c8_qscale = c8_qscale; a.c8_amax = c8_amax;
+    a.c8 = c8; a.ldc8 = N; a.c8_qscale = c8_qscale; a.c8_amax = c8_amax; a.c8_rowq = c8_rowq;
     a.M = M; a.N = N; a.K = K; a.n_valid = N; a.drop_p = drop_p; a.drop_key = drop_key;
     return kzv_gemm_nt_fp8(&a, epi, s);
 }
@@ -575,8 +602,10 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     KZV_TRY(wgrad_flush(m, s));          // cross-attention K/V of all layers + encoder_decoder_proj
     // also emits the masked bf16 copy the top ViT layer's fc2 backward starts from
     KZV_TRY(wait_cls(m, CLS_DY, s));
+    const KzvLnBwdF8 f8top{m->dy8, m->dy8_scale, m->dy8_rq, m->dy8_rqinv, m->f8_wnorm ? m->f8_wnorm + (m->Le - 1) : nullptr};
     KZV_TRY(kzv_ln_bwd_ex(m->denc_out, 0, m->x_last, m->stf, P + m->lnf_w, m->dx_e, 0, G + m->lnf_w, G + m->lnf_b, Me, He, m->Sa, 1, 0.f, 0, s,
-                          m->Le ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (m->Le - 1) + 2)));
+                          m->Le ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (m->Le - 1) + 2),
+                          (m->fp8 >= 2 && m->Le && !m->use_side) ? &f8top : nullptr));
     return KZV_OK;
 }
 
@@ -616,8 +645,15 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     // on entry dy_e = dropout-masked bf16 copy of dx_e for this layer's fc2 site (written by the LN backward above it)
     KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, G + e.fc2b));
     KZV_TRY(wait_cls(m, CLS_DBIG, s));
+    const bool f8g = m->fp8 >= 2 && !m->use_side;       // e4m3 input-gradient GEMMs of the MLP (the weight gradients keep reading bf16)
+    if (f8g)
+        KZV_TRY(gemm8(m->dy8, He, m->dy8_scale, m->w8t_fc2[i], Me, Fe, He, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe, 0.f, 0,
+                      m->dbig8, nullptr, nullptr, m->dy8_rq));
+    else
     KZV_TRY(gemm(m->dy_e, He, m->w_efc2[i], true, Me, Fe, He, Fe, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe));
     KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
+    if (f8g) KZV_TRY(gemm8(m->dbig8, Fe, m->dy8_rqinv, m->w8t_fc1[i], Me, He, Fe, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+    else
     KZV_TRY(gemm(m->dbig_e, Fe, m->w_efc1[i], true, Me, He, Fe, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
     KZV_TRY(wait_cls(m, CLS_DY, s));      // dy_e is rewritten below
     KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s,
@@ -632,8 +668,9 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
     // ... and the masked copy for the fc2 site of the layer below (layer 0 hands fp32 dx_e to the embedding backward)
     KZV_TRY(wait_cls(m, CLS_DY, s));
+    const KzvLnBwdF8 f8n{m->dy8, m->dy8_scale, m->dy8_rq, m->dy8_rqinv, (m->f8_wnorm && i > 0) ? m->f8_wnorm + (i - 1) : nullptr};
     KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_in, a.st1, P + e.ln1w, m->dx_e, 1, G + e.ln1w, G + e.ln1b, Me, He, 1, 0, 0.f, 0, s,
-                          i > 0 ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (i - 1) + 2)));
+                          i > 0 ? m->dy_e : nullptr, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * (i - 1) + 2), (f8g && i > 0) ? &f8n : nullptr));
     return KZV_OK;
 }
 
@@ -767,7 +804,11 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
 extern "C" int kzv_model_sync_weights(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "sync_weights: model not bound");
     KZV_TRY(kzv_cast_weights(m->d_desc, m->ndesc, m->cast_tiles, (hipStream_t)stream));
-    if (m->fp8) KZV_TRY(kzv_quant_rows(m->d_qdesc, m->nqdesc, m->qrows, (hipStream_t)stream));
+    if (m->fp8) {
+        if (m->fp8 >= 2 && hipMemsetAsync(m->f8_wnorm, 0, sizeof(float) * m->Le, (hipStream_t)stream) != hipSuccess)
+            return kzv_fail(KZV_E_HIP, "sync_weights: memset");
+        KZV_TRY(kzv_quant_rows(m->d_qdesc, m->nqdesc, m->qrows, (hipStream_t)stream));
+    }
     return KZV_OK;
 }
 
@@ -775,7 +816,7 @@ extern "C" int kzv_model_sync_weights(kzv_model* m, void* stream) {
 extern "C" int kzv_set_fp8(kzv_model* m, int mode) {
     if (!m) return kzv_fail(KZV_E_ARG, "set_fp8: null model");
     if (m->bound) return kzv_fail(KZV_E_STATE, "set_fp8: call before kzv_model_bind");
-    if (mode != 0 && mode != 1) return kzv_fail(KZV_E_ARG, "set_fp8: mode 0 (bf16) or 1 (e4m3 forward GEMMs of the encoder)");
+    if (mode < 0 || mode > 2) return kzv_fail(KZV_E_ARG, "set_fp8: mode 0 (bf16), 1 (e4m3 forward GEMMs of the encoder) or 2 (+ the MLP's input-gradient GEMMs)");
     if (mode && (m->He % 256 || m->Fe % 256))
         return kzv_fail(KZV_E_ARG, "set_fp8: encoder hidden %d and ffn %d must be multiples of 256 (128-byte K-tiles in pairs)", m->He, m->Fe);
     m->fp8 = mode;

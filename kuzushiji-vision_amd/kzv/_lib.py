@@ -43,7 +43,7 @@ class kzv_gemm_nt_fp8_args(C.Structure):
                 ("resid", C.c_void_p), ("ldr", C.c_int64), ("aux", C.c_void_p), ("ldaux", C.c_int64),
                 ("c8", C.c_void_p), ("ldc8", C.c_int64), ("c8_qscale", C.c_void_p), ("c8_amax", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("n_valid", C.c_int32),
-                ("drop_p", C.c_float), ("drop_key", C.c_uint32)]
+                ("drop_p", C.c_float), ("drop_key", C.c_uint32), ("c8_rowq", C.c_void_p)]
 
 
 class kzv_beam_state(C.Structure):

@@ -76,9 +76,10 @@ class TrOCRModel:
         self._h = h
         # fp8 weight path (BASELINE.json configs[4]; an extension -- the reference trains in bf16 autocast): the encoder's QKV,
         # fc1 and fc2 forward GEMMs read e4m3 weights and activations (include/kzv.h: kzv_set_fp8); backward stays bf16.
-        self.fp8 = bool(fp8)
+        # fp8 = True / 1: forward GEMMs; 2: also the MLP's two input-gradient GEMMs
+        self.fp8 = int(fp8)
         if self.fp8:
-            L.check(lib.kzv_set_fp8(h, 1), "kzv_set_fp8")
+            L.check(lib.kzv_set_fp8(h, self.fp8), "kzv_set_fp8")
         self._offsets, total = P.param_offsets(c)
         if lib.kzv_param_total(h) != total:
             raise L.KzvError("parameter table mismatch between kzv/params.py and libkzv")

@@ -89,10 +89,47 @@ def next_act_qscale(amax: float, prev: float = 1.0) -> float:
     return prev if amax <= 0 else 2.0 ** (math.floor(math.log2(FP8_MAX / amax)) - 1)
 
 
-def _linear_fp8(h, W, b, act_qscale=None):
+F8_BOUND = 1.4125          # csrc/layernorm.hip KZV_F8_BOUND: max gelu' (1.13) x 1.25
+
+
+class _LinearFp8Grad(torch.autograd.Function):
+    """fp8 mode 2: the value of _linear_fp8 forward, and an INPUT gradient computed on e4m3 operands like the build's d-fc2 /
+    d-fc1 GEMMs (weight and bias gradients stay those of the unquantised linear: the build's weight-gradient GEMMs read bf16).
+    kind "fc2": the arriving gradient rows are quantised by their own amax; the row multiplier of the NEXT gradient tensor
+    (st["rq"]) comes from the bound ||g row|| * max ||W column|| * F8_BOUND.  kind "fc1": rows quantised with st["rq"]."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, val, kind, st):
+        ctx.save_for_backward(h, W)
+        ctx.kind, ctx.st = kind, st
+        return val.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        h, W = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        h2 = h.reshape(-1, h.shape[-1])
+        wt = W.detach().to(torch.bfloat16).to(torch.float32).t().contiguous()      # rows = W columns, from the bf16 copy
+        wq, ws = quant_rows_e4m3(wt)
+        g32 = g2.detach().to(torch.float32)
+        if ctx.kind == "fc2":
+            gq, gs = quant_rows_e4m3(g32)
+            norm = torch.sqrt((g32 * g32).sum(dim=-1, keepdim=True))
+            cmax = torch.sqrt((wt * wt).sum(dim=-1)).max()
+            bound = F8_BOUND * norm * cmax
+            ctx.st["rq"] = torch.where(bound > 0, torch.tensor(FP8_MAX, dtype=torch.float32) / bound, torch.ones_like(bound))
+        else:
+            rq = ctx.st["rq"]
+            gq, gs = quant_e4m3(g32 * rq), 1.0 / rq
+        dt = g.dtype
+        gh = torch.matmul(gq.to(dt), wq.to(dt).t()) * gs.to(dt) * ws.to(dt).reshape(1, -1)
+        return gh.reshape(h.shape), torch.matmul(g2.t(), h2), g2.sum(dim=0), None, None, None
+
+
+def _linear_fp8(h, W, b, act_qscale=None, dgrad=None):
     """F.linear on e4m3 operands: W quantised per output row; h per token row, or per tensor with multiplier ``act_qscale``.
     Forward value = (hq Wq^T) * scales + b in h's dtype; gradients are those of the unquantised linear (the build's backward
-    reads the bf16 operands: straight-through)."""
+    reads the bf16 operands: straight-through) unless ``dgrad`` = (kind, state) asks for the e4m3 input gradient of mode 2."""
     wq, ws = quant_rows_e4m3(W)
     if act_qscale is None:
         hq, hs = quant_rows_e4m3(h)
@@ -101,6 +138,8 @@ def _linear_fp8(h, W, b, act_qscale=None):
         hs = torch.full(h.shape[:-1] + (1,), 1.0 / float(act_qscale), dtype=torch.float32)
     dt = h.dtype
     val = torch.matmul(hq.to(dt), wq.to(dt).t()) * hs.to(dt) * ws.to(dt).reshape(1, -1) + b.detach()
+    if dgrad is not None:
+        return _LinearFp8Grad.apply(h, W, b, val, dgrad[0], dgrad[1])
     plain = F.linear(h, W, b)
     return plain + (val - plain).detach()
 
@@ -140,13 +179,18 @@ def encoder_forward(cfg, sd, pixel_values, stages=None, masks=None, fp8=None):
         a = _attention(q, k, v, nh, None, masks, f"enc{i}_attn")
         x = x + _drop(F.linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"]), masks, f"enc{i}_o")
         h = _ln(x, sd[p + "layernorm_after.weight"], sd[p + "layernorm_after.bias"], cfg.ln_eps)
-        h = _gelu(lin(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        g8 = {} if (fp8 is not None and fp8.get("dgrad")) else None              # mode 2: the MLP's input gradients on e4m3 operands
+        if g8 is None:
+            h = _gelu(lin(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
+        else:
+            h = _gelu(_linear_fp8(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"], None, ("fc1", g8)))
         if fp8 is None:
             y = F.linear(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
         else:
             if stages is not None:
                 stages[f"enc{i}_act_amax"] = h.detach().abs().max()
-            y = _linear_fp8(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"], fp8["act_qscale"][i])
+            y = _linear_fp8(h, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"], fp8["act_qscale"][i],
+                            ("fc2", g8) if g8 is not None else None)
         x = x + _drop(y, masks, f"enc{i}_mlp")
         if stages is not None:
             stages[f"enc_layer{i}"] = x

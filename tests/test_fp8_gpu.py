@@ -138,6 +138,21 @@ def test_gemm_nt_fp8_epilogues(lib, M, N, K):
     y8 = _decode(c8).double() / 4.0
     yc = torch.clamp(y, -112.0, 112.0)                                   # 448 / 4: saturates, never NaN
     assert bool(((y8 - yc).abs() <= yc.abs() * 2.0 ** -4 * 1.01 + 2.0 ** -10 / 4.0 + 1e-4 * scale).all())
+    # DGELU: C = product * saved derivative (bf16), and its e4m3 copy quantised per ROW with given multipliers
+    der = torch.rand(M, N, device=DEV).bfloat16()
+    rowq = (0.5 + 4 * torch.rand(M, device=DEV))
+    c8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    a = L.kzv_gemm_nt_fp8_args(A=A8.data_ptr(), lda=K, B=B8.data_ptr(), ldb=K, a_scale=sa.data_ptr(), b_scale=sb.data_ptr(),
+                               C=(out := torch.empty(M, N, dtype=torch.bfloat16, device=DEV)).data_ptr(), ldc=N, aux=der.data_ptr(), ldaux=N,
+                               c8=c8.data_ptr(), ldc8=N, c8_rowq=rowq.data_ptr(), M=M, N=N, K=K, n_valid=N)
+    L.check(lib.kzv_gemm_nt_fp8(C.byref(a), L.EPI_DGELU, _st()), "gemm_nt_fp8 dgelu")
+    torch.cuda.synchronize()
+    dref = (ref - bias.cpu().double()) * der.cpu().double()
+    dscale = dref.abs().max().item()
+    assert (out.cpu().double() - dref).abs().max().item() < 2 ** -8 * dscale
+    d8 = _decode(c8).double() / rowq.cpu().double().unsqueeze(1)
+    dc = torch.maximum(torch.minimum(dref, 448.0 / rowq.cpu().double().unsqueeze(1)), -448.0 / rowq.cpu().double().unsqueeze(1))
+    assert bool(((d8 - dc).abs() <= dc.abs() * 2.0 ** -4 * 1.01 + (2.0 ** -10 / rowq.cpu().double()).unsqueeze(1) + 1e-4 * dscale).all())
     # dropout: the kernel's own mask, element index m * N + n (kzv_debug_dropout_mask)
     key = lib.kzv_drop_key(1234, 18)
     got = _gemm8(lib, A8, sa, B8, sb, L.EPI_RESID, M, N, K, bias, resid=resid, drop_p=0.1, key=key)
@@ -184,11 +199,13 @@ def test_fp8_switch_validates_geometry(tmp_path):
         _make(tiny_config(), tmp_path, fp8=True)                      # hidden 128: not a multiple of 256
 
 
-@pytest.mark.parametrize("dropout", [False, True])
-def test_fp8_step_matches_fake_quant_oracle(tmp_path, dropout):
+@pytest.mark.parametrize("dropout,mode", [(False, 1), (True, 1), (False, 2), (True, 2)])
+def test_fp8_step_matches_fake_quant_oracle(tmp_path, dropout, mode):
+    """mode 1: e4m3 forward GEMMs, straight-through gradients; mode 2: also the MLP's two input-gradient GEMMs on e4m3 operands
+    (gradient rows quantised by their amax / by the norm bound), the oracle's backward doing the same arithmetic."""
     cfg = _f8_config() if dropout else _no_dropout(_f8_config())
     B, Lh = 6, 24
-    m = _make(cfg, tmp_path, 5, fp8=True)
+    m = _make(cfg, tmp_path, 5, fp8=mode)
     m.trim_padding = False
     px, lab = synthetic_batch(cfg, B, Lh, seed=9, min_chars=4, max_chars=20)
     m.train()                               # dropout off = probabilities 0 in the config, still a training step
@@ -203,7 +220,7 @@ def test_fp8_step_matches_fake_quant_oracle(tmp_path, dropout):
         used = m.fp8_act_scales().tolist()
         assert used == pytest.approx(scales), f"step {step}: delayed multipliers"
         masks = step_masks(cfg, seed, B, Lh - 1) if dropout else None
-        r = O.forward_backward(cfg, sd, px, lab, want_stages=True, masks=masks, fp8={"act_qscale": used})
+        r = O.forward_backward(cfg, sd, px, lab, want_stages=True, masks=masks, fp8={"act_qscale": used, "dgrad": mode == 2})
         logits = logits.cpu().numpy()
         span = np.abs(r["logits"]).max()
         assert np.abs(logits - r["logits"]).max() < 1.5e-2 * span, f"step {step}"
@@ -214,6 +231,13 @@ def test_fp8_step_matches_fake_quant_oracle(tmp_path, dropout):
                 continue
             got = g[k].cpu().numpy().reshape(v.shape)
             assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, (step, k)
+        if mode == 2 and step == 0:
+            # the e4m3 input gradients are really what ran: the straight-through oracle is measurably further away
+            r1 = O.forward_backward(cfg, sd, px, lab, masks=masks, fp8={"act_qscale": used})
+            k = "encoder.encoder.layer.0.intermediate.dense.weight"
+            got = g[k].cpu().numpy().reshape(r["grads"][k].shape)
+            e2, e1 = np.abs(got - r["grads"][k]).max(), np.abs(got - r1["grads"][k]).max()
+            assert e2 < 0.5 * e1, (e2, e1)
         scales = [O.next_act_qscale(float(r["stages"][f"enc{i}_act_amax"]), scales[i]) for i in range(cfg.enc_layers)]
         assert all(s > 1.0 for s in scales)                           # GELU outputs here are O(1): the range gets used
 
