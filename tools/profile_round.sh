@@ -8,7 +8,6 @@ R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
@@ -18,5 +17,8 @@ cd $ROOT
 python tools/hbm_traffic.py $OUT/pmc_fetch/f_counter_collection.csv $OUT/pmc_write/w_counter_collection.csv > $OUT/hbm_traffic.json
 python tools/mfma_util.py $OUT/pmc_mfma/m_counter_collection.csv > $OUT/mfma_util.json
 cp $OUT/stats/b_kernel_stats.csv $OUT/bench_kernel_stats.csv
+# the bench line last, with this run's traffic summary in place (bench.py quotes roofline.traffic from profiles/ when the source hash matches)
+cp $OUT/hbm_traffic.json $ROOT/profiles/${R}_hbm_traffic.json
+python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/stats/b_kernel_trace.csv   # the raw traces are large; the summaries stay
 ls -la $OUT
