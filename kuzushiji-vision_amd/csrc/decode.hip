@@ -343,16 +343,28 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const BeamUpd p) {
     __shared__ unsigned char s_hit[16];
     const int img = blockIdx.x, lane = threadIdx.x;
     const int nb = p.nb, K = p.K, L = p.L;
+    // the ~40 state words of this image: one load per lane, together (read by lane 0 alone they were as many serial round trips)
+    __shared__ float s_lp[16], s_fsc[8];
+    __shared__ int64_t s_ix[16], s_flen[8];
+    __shared__ unsigned char s_fdone[8];
+    __shared__ unsigned char s_unsat;
+    if (lane < K) { s_lp[lane] = p.top_lp[(int64_t)img * K + lane]; s_ix[lane] = p.top_ix[(int64_t)img * K + lane]; }
+    if (lane >= 16 && lane < 16 + nb) {
+        const int i = lane - 16;
+        s_fsc[i] = p.fin_sc[img * nb + i]; s_fdone[i] = p.fin_done[img * nb + i]; s_flen[i] = p.fin_len[img * nb + i];
+    }
+    if (lane == 32) s_unsat = p.unsat[img];
+    __syncthreads();
     if (lane == 0) {
         float s2[16], msc[24];
         unsigned char mdone[24];
         bool all_hits = true, all_done = true;
-        for (int i = 0; i < nb; ++i) all_done = all_done && p.fin_done[img * nb + i];
+        for (int i = 0; i < nb; ++i) all_done = all_done && s_fdone[i];
         const float full_neg = (all_done && p.early) ? NEG : 0.f;
-        const float unsat_neg = p.unsat[img] ? 0.f : NEG;
+        const float unsat_neg = s_unsat ? 0.f : NEG;
         for (int k = 0; k < K; ++k) {
-            const int64_t ix = p.top_ix[(int64_t)img * K + k];
-            const float lp = p.top_lp[(int64_t)img * K + k];
+            const int64_t ix = s_ix[k];
+            const float lp = s_lp[k];
             const int src = (int)(ix / p.V), tok = (int)(ix - (int64_t)src * p.V);
             const bool hit = tok == p.eos || p.cur + 1 >= L;
             s_src[k] = src; s_tok[k] = tok; s_hit[k] = hit;
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const BeamUpd p) {
         for (int i = 0; i < nb; ++i) p.run_sc[img * nb + i] = run_new[i];
         // finished list: best nb of (old finished, stopped continuations of rank < nb)
         int64_t mlen[24];
-        for (int i = 0; i < nb; ++i) { msc[i] = p.fin_sc[img * nb + i]; mdone[i] = p.fin_done[img * nb + i]; mlen[i] = p.fin_len[img * nb + i]; }
+        for (int i = 0; i < nb; ++i) { msc[i] = s_fsc[i]; mdone[i] = s_fdone[i]; mlen[i] = s_flen[i]; }
         for (int k = 0; k < K; ++k) mlen[nb + k] = p.cur + 1;
         used = 0;
         float fsc_new[8]; unsigned char fd_new[8]; int64_t fl_new[8];
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const BeamUpd p) {
         const float best_open = run_new[0] / p.div_open;
         bool any = false;
         for (int i = 0; i < nb; ++i) any = any || best_open > (fd_new[i] ? fmin : NEG);
-        const bool un = p.unsat[img] && any;
+        const bool un = s_unsat && any;
         p.unsat[img] = un;
         if (un) atomicAdd(p.flags + 0, 1);
         if (!done_new) atomicAdd(p.flags + 1, 1);
