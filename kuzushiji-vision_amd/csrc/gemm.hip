@@ -418,7 +418,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     p.M = a->M; p.N = a->N; p.K = a->K; p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
     kzv_drop_params(a->drop_p, &p.drop_thr16, &p.drop_inv_keep);
     p.drop_key = a->drop_key;
-    p.strip = kzv_nt_strip();
+    p.strip = kzv_nt_strip() & 0xff;
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
     // large shapes: 256x256 eight-phase kernels.  The persistent one wins wherever its per-wave drain is light (one
@@ -476,7 +476,7 @@ extern "C" int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void
     p.M = a->M; p.N = a->N; p.K = a->K; p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
     kzv_drop_params(a->drop_p, &p.drop_thr16, &p.drop_inv_keep);
     p.drop_key = a->drop_key;
-    p.strip = kzv_nt_strip();
+    p.strip = kzv_nt_strip() & 0xff;
     p.a_scale = a->a_scale; p.b_scale = a->b_scale;
     p.c8 = (unsigned char*)a->c8; p.ldc8 = a->ldc8; p.c8_qscale = a->c8_qscale; p.c8_amax = a->c8_amax; p.c8_rowq = a->c8_rowq;
     hipStream_t s = (hipStream_t)stream;

@@ -75,7 +75,8 @@ struct TileSrc {            // where the next half-tiles of one half index (h) c
 };
 
 template <int EPI, bool F8>
-__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN, const int strip) {
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN, const int strip_in) {
+    const int strip = strip_in & 0xff;             // bit 8: the double-buffered bf16 drain (A/B knob KZV_BF16_DRAIN, default on)
     constexpr int ES = F8 ? 1 : 2;                 // bytes per operand element
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -223,8 +224,43 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 
     // ---- drain: this wave's 128x64 accumulators -> global, through its private LDS patch ----
+    // bf16 output without a second operand (the BF16 epilogue of interior tiles): bias added and converted BEFORE the transposition,
+    // so a row block is 2 KiB in the patch and two of them alternate -- block i + 1 is written while block i is read back.  The
+    // fp32 drain below is one LDS write -> read round trip per row block, 8 in a row (2.2 us per tile, all of it latency).
+    auto drain_bf16 = [&](int tm, int tn) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        char* patch = smem + RING_BYTES + w * 4096;                 // [2][16 rows][128 B], 8-byte chunks XOR row
+        const int l15 = ln & 15, g = ln >> 4;
+        const int prow = ln >> 4, pchunk = ln & 15;                 // read-back: 4 rows x 128 B per wave-instruction
+        const int nb0 = tn * 256 + wc * 64;
+        float bj[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) t = *(const float4*)(p.bias + nb0 + j * 16 + 4 * g);
+            bj[j][0] = t.x; bj[j][1] = t.y; bj[j][2] = t.z; bj[j][3] = t.w;
+        }
+        bf16_t* crow = (bf16_t*)p.C + (int64_t)(tm * 256 + wr * 128 + prow) * p.ldc + nb0 + pchunk * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            char* buf = patch + (i & 1) * 2048;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = acc[i][j];
+                *(uint2*)(buf + l15 * 128 + (((j * 4 + g) ^ l15) << 3)) = make_uint2(pack_bf2(a[0] + bj[j][0], a[1] + bj[j][1]), pack_bf2(a[2] + bj[j][2], a[3] + bj[j][3]));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = q * 4 + prow;
+                const uint2 v = *(const uint2*)(buf + row * 128 + ((pchunk ^ row) << 3));
+                nt_st((uint2*)(crow + (int64_t)(i * 16 + q * 4) * p.ldc), v);
+            }
+        }
+    };
     auto drain = [&](int tm, int tn, auto interiorc) {
         constexpr bool interior = decltype(interiorc)::value;
+        if constexpr (interior && EPI == KZV_EPI_BF16 && !F8) { if (strip_in & 0x100) { drain_bf16(tm, tn); return; } }
         int ln = lane;
         asm volatile("" : "+v"(ln));       // as in set_tile: keep the drain's address terms out of the K loop's live set
         // patch = one accumulator row block: [16 rows][64 cols] fp32 (256-B rows), 16-B chunks XOR (row & 15)
@@ -384,7 +420,12 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
 }  // namespace
 int kzv_nt_strip() {
     static int v = -1000;
-    if (v == -1000) { const char* e = getenv("KZV_NT_STRIP"); v = e ? atoi(e) : 3; }
+    if (v == -1000) {
+        const char* e = getenv("KZV_NT_STRIP"); v = e ? atoi(e) : 3;
+        if (v < 0 || v > 255) v = 0;
+        const char* d = getenv("KZV_BF16_DRAIN");
+        if (!d || atoi(d) != 0) v |= 0x100;
+    }
     return v;
 }
 namespace {
