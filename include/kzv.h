@@ -222,6 +222,23 @@ int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream);
  * never; KZV_ROWS_MAX_M), which takes the few-rows kernel the generation step (kzv_decode_step*) uses internally for its
  * M = batch GEMMs (one wave per 16x64 tile).  The per-op tests raise the threshold to check that kernel through this entry. */
 int kzv_set_rows_max_m(int n);
+/* The generation step's GEMMs with the decoder's LayerNorms folded in (hidden size 256): RoBERTa is post-LN, so every sub-layer
+ * output s is normalised once and LN(s) feeds one GEMM as A and one later residual add; at M = batch rows the consumers normalise
+ * themselves instead of a LayerNorm launch per sub-layer.  ln_a != NULL: A = LN(ln_a [M,256]) (K must be 256; A is ignored);
+ * ln_r != NULL: the RESID epilogue's residual = LN(ln_r [M,256]) (N must be 256).  Epilogues: BF16, F32, GELU, GELU_F32 with
+ * ln_a; RESID with ln_r.  Same arithmetic as kzv_layernorm_fwd + kzv_gemm_nt up to summation order. */
+typedef struct kzv_gemm_rows_ln_args {
+    const void* A; int64_t lda;       /* bf16 [M,K] or NULL with ln_a */
+    const void* B; int64_t ldb;       /* bf16 [n_valid,K] */
+    void* C; int64_t ldc;
+    const float* bias;
+    void* aux; int64_t ldaux;         /* GELU / GELU_F32 */
+    int32_t M, N, K, n_valid;
+    const float* ln_a; const float* ln_a_gamma; const float* ln_a_beta;
+    const float* ln_r; const float* ln_r_gamma; const float* ln_r_beta;
+    float eps;
+} kzv_gemm_rows_ln_args;
+int kzv_gemm_rows_ln(const kzv_gemm_rows_ln_args* a, int epilogue, void* stream);
 
 /* ---- fp8 weight path (BASELINE.json configs[4]: "fp8 MFMA weight path on CDNA4"; beyond the reference, which has no fp8) ----
  * C[M,N] = (A8[M,K] . B8[N,K]^T) * a_scale[m] * b_scale[n] (+bias) with the BF16 / GELU / RESID / DGELU epilogue of kzv_gemm_nt.

@@ -454,6 +454,22 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     return kzv_check_launch("gemm_nt");
 }
 
+// the generation step's GEMMs with the LayerNorm of their A operand and / or residual folded in (gemm_rows.hip)
+extern "C" int kzv_gemm_rows_ln(const kzv_gemm_rows_ln_args* a, int epilogue, void* stream) {
+    if (!a || !a->B || !a->C) return kzv_fail(KZV_E_ARG, "gemm_rows_ln: null operand");
+    if (!a->ln_a && !a->A) return kzv_fail(KZV_E_ARG, "gemm_rows_ln: needs A or ln_a");
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->N % 4 || a->ldc % 4 || a->ldb % 8 || (a->A && a->lda % 8)) return kzv_fail(KZV_E_ARG, "gemm_rows_ln: bad shape");
+    if (a->ln_a && (!a->ln_a_gamma || !a->ln_a_beta)) return kzv_fail(KZV_E_ARG, "gemm_rows_ln: ln_a needs gamma and beta");
+    if (a->ln_r && (!a->ln_r_gamma || !a->ln_r_beta)) return kzv_fail(KZV_E_ARG, "gemm_rows_ln: ln_r needs gamma and beta");
+    if ((epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32) && (!a->aux || a->ldaux % 4)) return kzv_fail(KZV_E_ARG, "gemm_rows_ln: GELU needs aux");
+    NtParams p{};
+    p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.C = a->C; p.bias = a->bias; p.aux = (bf16_t*)a->aux;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldc; p.ldaux = a->ldaux;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.n_valid = a->n_valid > 0 ? a->n_valid : a->N;
+    p.drop_inv_keep = 1.f;
+    return kzv_rows_ln_launch(p, epilogue, a->ln_a, a->ln_a_gamma, a->ln_a_beta, a->ln_r, a->ln_r_gamma, a->ln_r_beta, a->eps, (hipStream_t)stream);
+}
+
 // fp8 (e4m3) operands with per-row scales, block-scaled MFMA at twice the bf16 rate (gemm_nt256p.hip).
 extern "C" int kzv_gemm_nt_fp8(const kzv_gemm_nt_fp8_args* a, int epilogue, void* stream) {
     if (!a || !a->A || !a->B || !a->C || !a->a_scale || !a->b_scale) return kzv_fail(KZV_E_ARG, "gemm_nt_fp8: null operand or scale");

@@ -99,3 +99,6 @@ int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s);
 // training step and its parity tests keep running the tiled kernels at every size.
 int kzv_rows_launch(const NtParams& p, int epilogue, hipStream_t s);
 struct KzvRowsScope { KzvRowsScope(); ~KzvRowsScope(); };
+// the few-rows kernel with the decoder's LayerNorm folded into its A operand and / or its residual (gemm_rows.hip)
+int kzv_rows_ln_launch(const NtParams& p, int epilogue, const float* ln_a, const float* ga, const float* ba, const float* ln_r, const float* gr,
+                       const float* br, float eps, hipStream_t s);

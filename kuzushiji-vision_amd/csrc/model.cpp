@@ -933,12 +933,67 @@ static int gemm_ln(kzv_model* m, const bf16_t* A, int64_t lda, const W16& w, int
     return kzv_ln_fwd_ex(tmp32, gamma, beta, y16, y32, stats, M, Hd, m->c.ln_eps, 1, 0, 0.f, 0, s);
 }
 
+// a generation-step GEMM whose A operand is LN(ln_a) and / or whose RESID residual is LN(ln_r) (hidden size 256: gemm_rows.hip)
+static int gemm_f(const bf16_t* A, int64_t lda, const W16& w, int M, int N, int K, int n_valid, const float* bias, void* C, int64_t ldc, int epi,
+                  hipStream_t s, void* aux, int64_t ldaux, const float* ln_a, const float* ga, const float* ba, const float* ln_r, const float* gr,
+                  const float* br, float eps) {
+    kzv_gemm_rows_ln_args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.B = w.w; a.ldb = K; a.C = C; a.ldc = ldc; a.bias = bias; a.aux = aux; a.ldaux = ldaux;
+    a.M = M; a.N = N; a.K = K; a.n_valid = n_valid;
+    a.ln_a = ln_a; a.ln_a_gamma = ga; a.ln_a_beta = ba; a.ln_r = ln_r; a.ln_r_gamma = gr; a.ln_r_beta = br; a.eps = eps;
+    return kzv_gemm_rows_ln(&a, epi, s);
+}
+
+// Hidden size 256: no LayerNorm launch at all -- each sub-layer output (fp32) stays un-normalised in memory and its two consumers
+// (one GEMM's A operand, one later residual add) normalise it themselves (gemm_rows_ln_kernel).  20 launches fewer per token.
+static int decode_step_body_fused(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const int* tptr, const unsigned char* d_valid,
+                                  int64_t ld_valid, float* d_logits, hipStream_t s) {
+    const kzv_config& c = m->c;
+    const int B = m->B, Hd = m->Hd, Fd = m->Fd, T = m->T;
+    float* P = m->P;
+    const float eps = c.ln_eps;
+    bf16_t* cache = m->kvc[m->kv_cur];
+    const int64_t plane = (int64_t)B * T * Hd;
+    KZV_TRY(kzv_embed_gather(d_tokens, 1, d_posids, P + m->word, P + m->dtype, P + m->dpos, m->emb_sum, B, 1, Hd, s));
+    const float* src = m->emb_sum; const float* sg = P + m->eln_w; const float* sb = P + m->eln_b;      // x = LN(src; sg, sb), never stored
+    for (int i = 0; i < m->Ld; ++i) {
+        DecAct& a = m->da[i];
+        const DecLayerP& d = m->dp[i];
+        KZV_TRY(gemm_f(nullptr, 0, m->w_dqkv[i], B, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s, nullptr, 0, src, sg, sb, nullptr, nullptr, nullptr, eps));
+        KZV_TRY(kzv_attn_decode(a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, cache + (int64_t)(2 * i) * plane, cache + (int64_t)(2 * i + 1) * plane,
+                                (int64_t)T * Hd, 64, d_valid, ld_valid, a.ctx, Hd, B, c.dec_heads, tptr ? T : t + 1, t, s, tptr, 1,
+                                m->rt_cur >= 0 ? m->rowtab[m->rt_cur] : nullptr, T, (int64_t)T * 64));
+        KZV_TRY(gemm_f(a.ctx, Hd, m->w_do[i], B, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, nullptr, 0, nullptr, nullptr, nullptr, src, sg, sb, eps));
+        KZV_TRY(gemm_f(nullptr, 0, m->w_dcq[i], B, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s, nullptr, 0, a.s1, P + d.ln1w, P + d.ln1b, nullptr, nullptr, nullptr, eps));
+        {
+            const int64_t img = (int64_t)m->npa * Hd, plane2 = (int64_t)m->Be * img;
+            KZV_TRY(kzv_attn_decode(a.cq, Hd, nullptr, nullptr, 0, m->ckv_dec + (int64_t)(2 * i) * plane2, m->ckv_dec + (int64_t)(2 * i + 1) * plane2,
+                                    img, 64, nullptr, 0, a.cctx, Hd, B, c.dec_heads, m->npa, -1, s, nullptr, B / m->Be, nullptr, 0, (int64_t)m->npa * 64));
+        }
+        KZV_TRY(gemm_f(a.cctx, Hd, m->w_dco[i], B, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, nullptr, 0, nullptr, nullptr, nullptr, a.s1, P + d.ln1w, P + d.ln1b, eps));
+        KZV_TRY(gemm_f(nullptr, 0, m->w_dfc1[i], B, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, a.pre, Fd, a.s2, P + d.ln2w, P + d.ln2b, nullptr, nullptr, nullptr, eps));
+        KZV_TRY(gemm_f(a.act, Fd, m->w_dfc2[i], B, Hd, Fd, Hd, P + d.fc2b, a.s3, Hd, KZV_EPI_RESID, s, nullptr, 0, nullptr, nullptr, nullptr, a.s2, P + d.ln2w, P + d.ln2b, eps));
+        src = a.s3; sg = P + d.ln3w; sb = P + d.ln3b;
+    }
+    KZV_TRY(gemm_f(nullptr, 0, m->w_hd, B, Hd, Hd, Hd, P + m->hd_b, m->hd_gelu, Hd, KZV_EPI_GELU_F32, s, m->hd_pre, Hd, src, sg, sb, nullptr, nullptr, nullptr, eps));
+    if (m->V % 4 == 0)
+        return gemm_f(nullptr, 0, m->w_word, B, m->V, Hd, m->V, P + m->hbias, d_logits, m->V, KZV_EPI_F32, s, nullptr, 0, m->hd_gelu, P + m->hln_w, P + m->hln_b,
+                      nullptr, nullptr, nullptr, eps);
+    KZV_TRY(gemm_f(nullptr, 0, m->w_word, B, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s, nullptr, 0, m->hd_gelu, P + m->hln_w, P + m->hln_b,
+                   nullptr, nullptr, nullptr, eps));
+    return kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s);
+}
+
 static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const int* tptr, const unsigned char* d_valid,
                             int64_t ld_valid, float* d_logits, hipStream_t s) {
     const kzv_config& c = m->c;
     const int B = m->B, Hd = m->Hd, Fd = m->Fd, T = m->T;
     float* P = m->P;
     const float eps = c.ln_eps;
+    static int fuse_ln = -1;
+    if (fuse_ln < 0) { const char* e = getenv("KZV_DECODE_FUSE_LN"); fuse_ln = e ? atoi(e) : 1; }
+    if (fuse_ln && Hd == 256 && B <= 4096) return decode_step_body_fused(m, d_tokens, d_posids, t, tptr, d_valid, ld_valid, d_logits, s);
     KzvRowsScope rows_scope;                     // M = B rows: every GEMM of the step takes the few-rows kernel (gemm_rows.hip)
     bf16_t* cache = m->kvc[m->kv_cur];
     const int64_t plane = (int64_t)B * T * Hd;  // one layer's K (or V) cache

@@ -46,6 +46,14 @@ class kzv_gemm_nt_fp8_args(C.Structure):
                 ("drop_p", C.c_float), ("drop_key", C.c_uint32), ("c8_rowq", C.c_void_p)]
 
 
+class kzv_gemm_rows_ln_args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("bias", C.c_void_p), ("aux", C.c_void_p), ("ldaux", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("n_valid", C.c_int32),
+                ("ln_a", C.c_void_p), ("ln_a_gamma", C.c_void_p), ("ln_a_beta", C.c_void_p),
+                ("ln_r", C.c_void_p), ("ln_r_gamma", C.c_void_p), ("ln_r_beta", C.c_void_p), ("eps", C.c_float)]
+
+
 class kzv_beam_state(C.Structure):
     _fields_ = [("batch", C.c_int32), ("num_beams", C.c_int32), ("max_len", C.c_int32), ("vocab", C.c_int32), ("eos_id", C.c_int32),
                 ("run_seq_in", C.c_void_p), ("run_seq_out", C.c_void_p), ("fin_seq_in", C.c_void_p), ("fin_seq_out", C.c_void_p),
@@ -108,6 +116,7 @@ SYMBOLS = {
     "kzv_lerp_params": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "kzv_gemm_nt": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
     "kzv_set_rows_max_m": (C.c_int, [C.c_int]),
+    "kzv_gemm_rows_ln": (C.c_int, [C.POINTER(kzv_gemm_rows_ln_args), C.c_int, _P]),
     "kzv_gemm_nt_fp8": (C.c_int, [C.POINTER(kzv_gemm_nt_fp8_args), C.c_int, _P]),
     "kzv_quant_rows_fp8": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
     "kzv_layernorm_fwd_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),

@@ -244,13 +244,17 @@ def test_generate_is_consistent_and_overfit_model_reproduces_labels(tmp_path):
     assert cers == [0.0, 0.0, 0.0, 0.0], cers
 
 
-def test_kv_cached_step_equals_the_prefix_recompute(tmp_path):
+@pytest.mark.parametrize("wide", [False, True])
+def test_kv_cached_step_equals_the_prefix_recompute(tmp_path, wide):
     """kzv_decode_step (one token against cached keys / values) against kzv_decode_logits (teacher-forced pass over the
     whole prefix) on the same ids, every step, including rows that have already ended (padding), and after a beam-style
     re-ordering of the cache rows; then the two generate() modes end to end (greedy and beam)."""
     import ctypes as C
+    import dataclasses
     from kzv import _lib as L
     cfg = _no_dropout(tiny_config())
+    if wide:        # decoder hidden 256: the generation step folds every LayerNorm into the GEMMs around it (gemm_rows_ln_kernel)
+        cfg = dataclasses.replace(cfg, dec_hidden=256, dec_heads=4, dec_ffn=768)
     m = _make(cfg, tmp_path, 9)
     m.eval()
     B, Lh = 6, 14

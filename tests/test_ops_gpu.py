@@ -361,3 +361,45 @@ def test_beam_topk_matches_log_softmax_plus_topk(lib, B, nb, V):
         assert out_ix[0, :nb].tolist() == [k * V + best for k in range(nb)]
         assert float(out_lp[0, 0]) == float(out_lp[0, nb - 1])
     assert lib.kzv_beam_topk(logits.data_ptr(), ld, sc.data_ptr(), B, 9, V, 16, out_lp.data_ptr(), out_ix.data_ptr(), _st()) != 0      # > 8 beams
+
+
+@pytest.mark.parametrize("M,N,K,epi,which", [(1, 256, 256, 0, "a"), (100, 768, 256, 0, "a"), (256, 768, 256, 2, "a"), (37, 256, 256, 5, "a"),
+                                              (1024, 4300, 256, 1, "a"), (256, 256, 256, 3, "r"), (1000, 256, 768, 3, "r"), (5, 256, 1024, 3, "r")])
+def test_gemm_rows_with_folded_layernorm(lib, M, N, K, epi, which):
+    """kzv_gemm_rows_ln (generation step, hidden 256): A = LN(x) or residual = LN(x) computed inside the GEMM, against
+    kzv_layernorm_fwd followed by kzv_gemm_nt on the few-rows kernel (summation order differs: a bf16 step here and there)."""
+    torch.manual_seed(M + N + K + epi)
+    x = torch.randn(M, 256, device=DEV) * 2 + 0.3
+    gamma = torch.randn(256, device=DEV)
+    beta = torch.randn(256, device=DEV)
+    B = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
+    bias = torch.randn(N, device=DEV)
+    y16 = torch.empty(M, 256, dtype=torch.bfloat16, device=DEV)
+    y32 = torch.empty(M, 256, device=DEV)
+    L.check(lib.kzv_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y16.data_ptr(), y32.data_ptr(), None, M, 256, 1e-12, _st()), "ln")
+    f32out = epi in (L.EPI_F32, L.EPI_RESID, 5)
+    out = torch.empty(M, N, dtype=torch.float32 if f32out else torch.bfloat16, device=DEV)
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if epi in (2, 5) else None
+    aux2 = torch.empty_like(aux) if aux is not None else None
+    L.check(lib.kzv_set_rows_max_m(4096), "rows_max_m")
+    try:
+        if which == "a":
+            ref = _gemm_nt(lib, y16, B, epi, bias, aux=aux)
+            a = L.kzv_gemm_rows_ln_args(A=None, lda=0, B=B.data_ptr(), ldb=K, C=out.data_ptr(), ldc=N, bias=bias.data_ptr(), aux=L.ptr(aux2), ldaux=N,
+                                        M=M, N=N, K=K, n_valid=N, ln_a=x.data_ptr(), ln_a_gamma=gamma.data_ptr(), ln_a_beta=beta.data_ptr(), eps=1e-12)
+        else:
+            A = torch.randn(M, K, device=DEV).bfloat16()
+            ref = _gemm_nt(lib, A, B, epi, bias, resid=y32)
+            a = L.kzv_gemm_rows_ln_args(A=A.data_ptr(), lda=K, B=B.data_ptr(), ldb=K, C=out.data_ptr(), ldc=N, bias=bias.data_ptr(), M=M, N=N, K=K, n_valid=N,
+                                        ln_r=x.data_ptr(), ln_r_gamma=gamma.data_ptr(), ln_r_beta=beta.data_ptr(), eps=1e-12)
+        L.check(lib.kzv_gemm_rows_ln(C.byref(a), epi, _st()), "gemm_rows_ln")
+    finally:
+        L.check(lib.kzv_set_rows_max_m(0), "rows_max_m")
+    torch.cuda.synchronize()
+    scale = max(1.0, ref.float().abs().max().item())
+    tol = (2e-5 if which == "r" else 3e-3) * scale + (0 if f32out else 2 ** -8 * scale)
+    assert (out.float() - ref.float()).abs().max().item() < tol
+    if aux is not None:
+        assert (aux2.float() - aux.float()).abs().max().item() < 2e-2
+    bad = L.kzv_gemm_rows_ln_args(A=None, lda=0, B=B.data_ptr(), ldb=K, C=out.data_ptr(), ldc=N, M=M, N=N, K=K, n_valid=N)
+    assert lib.kzv_gemm_rows_ln(C.byref(bad), epi, _st()) != 0          # nothing to normalise and no A
