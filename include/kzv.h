@@ -141,8 +141,11 @@ int kzv_greedy_update(const float* d_logits, int64_t ld, int vocab, int64_t* d_i
  * against HF on the CPU).  State arrays live in caller memory for the whole generation; token rows are double-buffered (the
  * caller swaps run_seq_in/out and fin_seq_in/out after every call).  `cur` = index of the token being chosen (1 = first after
  * BOS).  Outputs: d_rows [batch * num_beams] = the former flat row every running beam continues from (for kzv_decode_reorder),
- * d_flags [3] = {images whose open beams may still improve, images whose finished list is not full, images with a continuation
- * that did not stop}: the loop goes on iff flags[0] > 0 && !(early_stopping && flags[1] == 0) && flags[2] > 0. */
+ * d_flags [5]: [0..2] = {images whose open beams may still improve, images whose finished list is not full, images with a
+ * continuation that did not stop}: the loop goes on iff flags[0] > 0 && !(early_stopping && flags[1] == 0) && flags[2] > 0.  That
+ * test is also taken on the device: d_flags[3] becomes 1 when the search has ended and d_flags[4] holds the number of updates
+ * applied; calls issued after the end change nothing (the caller may read d_flags only every few steps; the valid token rows are
+ * then the buffers written by update number d_flags[4]).  The call with cur == 1 resets d_flags[3..4]. */
 typedef struct kzv_beam_state {
     int32_t batch, num_beams, max_len, vocab, eos_id;
     const int64_t* run_seq_in; int64_t* run_seq_out;     /* [batch, num_beams, max_len] */

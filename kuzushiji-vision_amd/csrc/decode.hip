@@ -332,7 +332,7 @@ struct BeamUpd {
     const int64_t* fin_seq_in; int64_t* fin_seq_out;              // [B, nb, L]
     float* run_sc; float* fin_sc; unsigned char* fin_done; int64_t* fin_len; unsigned char* unsat;   // [B, nb] / [B]
     int64_t* rows;                                                // [B * nb]: former flat row each running beam continues from
-    int* flags;                                                   // [3]: images still unsatisfied, images whose finished list is not full, images with a continuation that did not stop
+    int* flags;                                                   // [5]: images still unsatisfied, images whose finished list is not full, images with a continuation that did not stop; [3] = stopped, [4] = updates applied
     int nb, K, L, V, cur, eos, early;
     float div_fin, div_open;                                      // (cur + 1 - prompt) ** length_penalty, (cur + 1 + 1 - prompt - 1) ** length_penalty as fp32
 };
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const BeamUpd p) {
     __shared__ unsigned char s_hit[16];
     const int img = blockIdx.x, lane = threadIdx.x;
     const int nb = p.nb, K = p.K, L = p.L;
+    if (p.flags[3]) return;                      // the search has ended (beam_stop_kernel): steps issued before the host noticed change nothing
     // the ~40 state words of this image: one load per lane, together (read by lane 0 alone they were as many serial round trips)
     __shared__ float s_lp[16], s_fsc[8];
     __shared__ int64_t s_ix[16], s_flen[8];
@@ -482,6 +483,14 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(const float* __restr
     }
 }
 
+// after beam_update: the loop condition of HF _beam_search, kept on the device so that the host may look only every few steps
+__global__ void beam_stop_kernel(int* flags, int early, int cur) {
+    if (flags[3]) return;
+    flags[4] = cur;                              // updates applied so far (cur counts from 1)
+    const bool go_on = flags[0] > 0 && !(early && flags[1] == 0) && flags[2] > 0;
+    if (!go_on) flags[3] = 1;
+}
+
 __global__ void step_inc_kernel(int* t) { *t += 1; }
 
 }  // namespace
@@ -553,12 +562,13 @@ extern "C" int kzv_beam_update(const kzv_beam_state* st, const float* d_top_scor
     if (cur < 1 || cur >= st->max_len) return kzv_fail(KZV_E_ARG, "beam_update: position outside 1..max_len-1");
     if (st->run_seq_in == st->run_seq_out || st->fin_seq_in == st->fin_seq_out) return kzv_fail(KZV_E_ARG, "beam_update: in and out token rows must differ");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(d_flags, 0, 3 * sizeof(int), s) != hipSuccess) return kzv_fail(KZV_E_HIP, "beam_update: memset");
+    if (hipMemsetAsync(d_flags, 0, (cur == 1 ? 5 : 3) * sizeof(int), s) != hipSuccess) return kzv_fail(KZV_E_HIP, "beam_update: memset");
     BeamUpd p{d_top_scores, d_top_index, st->run_seq_in, st->run_seq_out, st->fin_seq_in, st->fin_seq_out, st->run_scores, st->fin_scores,
               st->fin_done, st->fin_len, st->unsatisfied, d_rows, d_flags, st->num_beams, 2 * st->num_beams, st->max_len, st->vocab, cur,
               st->eos_id, early_stopping ? 1 : 0,
               (float)pow((double)(cur + 1 - 1), (double)length_penalty), (float)pow((double)(cur + 1 - 1), (double)length_penalty)};
     hipLaunchKernelGGL(beam_update_kernel, dim3(st->batch), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(beam_stop_kernel, dim3(1), dim3(1), 0, s, d_flags, early_stopping ? 1 : 0, cur);
     return kzv_check_launch("beam_update");
 }
 

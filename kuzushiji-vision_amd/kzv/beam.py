@@ -157,10 +157,12 @@ def beam_search_fused(step, reorder, batch, num_beams, max_len, vocab, pad_id, b
         rows, flags = update(st, top_lp, top_ix, cur)
         st["cur_buf"] ^= 1
         cur += 1
-        f = flags.tolist()                                         # the one host synchronisation of the step
-        go_on = f[0] > 0 and not (f[1] == 0 and early_stopping is True) and f[2] > 0
-        if not go_on:
-            break
+        # the stop test is taken on the device (flags[3]); the host looks every 4th step -- updates issued past the end are no-ops
+        if (cur - 1) % 4 == 0 or cur >= max_len:
+            f = flags.tolist()
+            if f[3]:
+                st["cur_buf"] = f[4] & 1                               # the buffers written by the last update that was applied
+                break
         reorder(rows, cur - 1)
     fin_seq = st["fin_seq"][st["cur_buf"]]
     width = int(st["fin_len"][:, 0].max())
@@ -179,7 +181,7 @@ def make_device_hooks(batch, num_beams, max_len, vocab, eos_id, early_stopping, 
     top_lp = torch.empty(B, 2 * nb, dtype=torch.float32, device=device)
     top_ix = torch.empty(B, 2 * nb, dtype=torch.int64, device=device)
     rows_buf = torch.empty(B * nb, dtype=torch.int64, device=device)
-    flags_buf = torch.empty(3, dtype=torch.int32, device=device)
+    flags_buf = torch.zeros(5, dtype=torch.int32, device=device)
     keep = {}
 
     def topk(raw, run_sc):                # log_softmax + beam score + top 2 * nb per image in one launch

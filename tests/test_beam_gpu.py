@@ -40,9 +40,9 @@ def test_fused_beam_search_equals_the_torch_statement(B, nb, V, T, eos_bias, ear
                                    return_state=True)
     torch.cuda.synchronize()
     assert torch.equal(got.cpu(), want.cpu())
-    assert len(parents) == n_ref                                   # the same number of steps
+    assert n_ref <= len(parents) <= n_ref + 4                      # the host looks at the stop flag every 4th step
     for a, b in zip(parents, ref_parents):
-        assert torch.equal(a, b)                                   # and the same re-parenting at every step
+        assert torch.equal(a, b)                                   # the same re-parenting at every step of the search
 
 
 @pytest.mark.parametrize("B,V,T,eos_bias", [(5, 41, 12, 2.0), (256, 4300, 20, 5.0), (3, 157, 9, -5.0)])
