@@ -480,3 +480,19 @@ def test_reference_fixtures_through_the_256x256_gemm_kernels(tmp_path):
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_layernorm_folded_decode_step_equals_the_unfolded_one(tmp_path):
+    """Decoder hidden 256: the generation step folds every LayerNorm into the GEMMs around it (KZV_DECODE_FUSE_LN, read once per
+    process).  Two child processes run the same eleven steps with the switch on and off: the logits agree to bf16 noise."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_decode_worker.py")
+    got = {}
+    for mode in ("1", "0"):
+        out = tmp_path / f"l{mode}.npy"
+        subprocess.run([sys.executable, worker, str(out), str(tmp_path / f"w{mode}")], check=True, env=dict(os.environ, KZV_DECODE_FUSE_LN=mode), timeout=600)
+        got[mode] = np.load(out)
+    span = np.abs(got["0"]).max()
+    assert np.isfinite(got["1"]).all() and got["1"].shape == got["0"].shape
+    assert np.abs(got["1"] - got["0"]).max() < 5e-3 * span
