@@ -11,7 +11,8 @@
  * sized by kzv_workspace_bytes.  The library itself allocates only small or grow-only scratch on the current device,
  * kept for the life of the process (one device per process): a 4 KiB page of zeros (LDS-DMA loads of out-of-range
  * tile rows are pointed at it), the LayerNorm gamma/beta partial rows (512 KiB), the gemm_tn256 partial-tile
- * workspace (<= 66 MB) and, per model handle, the KV cache of kzv_decode_step (freed by kzv_model_destroy).
+ * workspace (<= 66 MB) and, per model handle, the generation path's KV cache, beam row tables and decode-layout copy of the
+ * cross-attention K/V (allocated at the first kzv_decode_step / kzv_decode_begin, freed by kzv_model_destroy).
  * Other global state: the last-error string, the profiling slots and the CU reserve.  `stream` is a hipStream_t passed as void*.
  * One model handle per process/GPU; a handle is not re-entrant.
  */
