@@ -344,8 +344,9 @@ uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
  *   KZV_SITE_DEC_LAYER(i, 0/2) self / cross attention-probability dropout              (HF modeling_roberta.py:178)
  *   KZV_SITE_DEC_LAYER(i, 1/3) RobertaSelfOutput.dropout of the self / cross block     (HF modeling_roberta.py:338)
  *   KZV_SITE_DEC_LAYER(i, 4)   RobertaOutput.dropout (FFN)                             (HF modeling_roberta.py:396)
- * Element index of a [rows, cols] hidden site: row * cols + col; of an attention site: ((b * heads + h) * Sq + q) * Sk_even
- * + key with Sk_even = (Sk + 1) & ~1.  Rows are token rows of the PACKED decoder ([B, t_active], kzv_set_active_length). */
+ * Element index of a [rows, cols] hidden site: row * cols + col (kzv_debug_dropout_mask); an attention site is indexed by
+ * (b * heads + h, q, key) (kzv_debug_attn_dropout_mask).  Rows are token rows of the PACKED decoder ([B, t_active],
+ * kzv_set_active_length). */
 #define KZV_SITE_ENC_EMB 1u
 #define KZV_SITE_ENC_LAYER(i, k) (16u + 4u * (uint32_t)(i) + (uint32_t)(k))
 #define KZV_SITE_DEC_EMB 1000u
@@ -356,6 +357,12 @@ uint32_t kzv_drop_key(uint64_t seed, uint32_t site);
  * Uses the same device hash as every fused dropout epilogue, so a test can hand the exact masks of a training step to the
  * CPU oracle and compare logits, loss and every gradient with dropout ON. */
 int kzv_debug_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t ld_index, float* d_out, void* stream);
+/* The same for an ATTENTION-PROBABILITY site (KZV_SITE_*_LAYER(i, 0 / 2); F.dropout on the softmax output, HF modeling_vit.py:184,
+ * modeling_roberta.py:178): d_out fp32 [pairs * Sq, Sk], pairs = batch * heads.  These sites draw their bits from one 32-bit hash
+ * per 4 x 4 block of a (batch, head)'s [Sq, Sk] matrix and a 16-bit multiply per element (kzv_common.h, "attention-probability
+ * dropout"; numpy statement: oracle/attn_dropout.py), because the forward kernel holds 4 keys of one query per lane and the
+ * backward kernel 4 queries of one key, and this costs the same few instructions in both orientations. */
+int kzv_debug_attn_dropout_mask(uint32_t key, float p, int64_t pairs, int32_t Sq, int32_t Sk, float* d_out, void* stream);
 
 /* Data-parallel runs: the GEMM kernels that put exactly one workgroup on every CU (persistent gemm_nt256p, gemm_tn256)
  * double their time when a concurrently running collective holds a few CUs.  With n > 0 the launchers leave n CUs

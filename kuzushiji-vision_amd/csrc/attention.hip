@@ -22,9 +22,17 @@
 
 namespace {
 
-// Geometry is a template parameter: KT key tiles of 16 (LDS images hold SP = 16*KT rows), NW waves per workgroup.
-// (12, 4) serves Sq, Sk <= 192 (64x640 crops: 161 tokens); (18, 4 forward / 8 backward) serves <= 288 tokens
+// Geometry is a template parameter: NKT key tiles of 16 (EXACT: the launch has exactly NKT of them, so the tile loops carry no
+// branches), 4 waves per workgroup (8 in the <= 288-token backward).  Exact instances exist for the two hot shapes -- 11 tiles
+// (64x640 crops: 161 tokens) and 10 (cross attention over 160 patch tokens) -- the generic ones serve <= 192 and <= 288 tokens
 // (the reference's default 1024x64 columns: 257 tokens).
+//
+// Both kernels are bound by VALU ISSUE, not by MFMA or HBM (round 3 measurement: a wave issues one vector instruction per ~4.7
+// cycles whatever it is -- v_mul_lo_u32 included -- and the round-2 kernels spent ~1,300 instructions per 16-query tile
+// forward and ~1,700 per 32-query slab backward).  So the code below is written for instruction count: LDS addresses are
+// per-lane constants + immediates, the softmax normalisation and 1 / P(keep) are applied to the 16 outputs instead of the
+// 44 probabilities, the dropout bits come from the packed 4 x 4-block generator of kzv_common.h, and dS crosses LDS as
+// packed 8-byte pieces of a [key][query] image that the dQ product reads back transposed (ds_read_b64_tr_b16).
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnP {
@@ -59,25 +67,20 @@ __device__ __forceinline__ bf16x4 frag_tr(const char* img, int rb, int c2, int l
     return lds_tr16(img + row * 128 + ((chunk ^ (row & 7)) << 4) + (l15 & 1) * 8);
 }
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
-__device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
-    const unsigned u0 = pack_bf2(a[0], a[1]), u1 = pack_bf2(a[2], a[3]), u2 = pack_bf2(b[0], b[1]), u3 = pack_bf2(b[2], b[3]);
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    return __builtin_bit_cast(bf16x8, (u32x4){u0, u1, u2, u3});
-}
-__device__ __forceinline__ float keep_of(const AttnP& p, unsigned e) {
-    const unsigned bits = drop_bits(p.key, e >> 1);
-    return drop_keep(bits, e & 1, p.thr16, p.inv_keep);
-}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ bf16x8 words8(unsigned a, unsigned b, unsigned c, unsigned d) { return __builtin_bit_cast(bf16x8, (u32x4){a, b, c, d}); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 // ================================================================================================ forward
-// launch bounds = the occupancy the LDS images allow anyway (3 workgroups per CU at 192 key rows, 2 at 288): with the
-// default target hipcc squeezed the kernel into 112 VGPRs and spent ~45 % of its VALU slots on v_accvgpr moves
-template <int MODE, int KT>
-__global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const AttnP p) {
-    constexpr int SP = KT * 16, IMG = SP * 128;
+// launch bounds = the occupancy the LDS images allow anyway (3 workgroups per CU at <= 192 key rows, 2 at 288)
+template <int MODE, int NKT, bool EXACT>
+__global__ __launch_bounds__(256, NKT <= 12 ? 3 : 2) void attn_fwd_kernel(const AttnP p) {
+    constexpr int NKP = (NKT + 1) / 2;                // PV steps of 32 keys
+    constexpr int SPK = NKT * 16, SPV = NKP * 32;     // K image rows; V image rows (zero rows up to the pair boundary)
+    constexpr int QI = (NKT + 3) / 4;                 // query tiles per wave (the host checks ceil(Sq / 16) <= 4 * QI)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem; char* Vs = smem + IMG;
-    int* kvalid = (int*)(smem + 2 * IMG);
+    char* Ks = smem; char* Vs = smem + SPK * 128;
+    int* kvalid = (int*)(smem + (SPK + SPV) * 128);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
 #ifdef KZV_STAMPS      // diagnostic build: workgroup timeline of a few blocks into the (unused in forward) dQ buffer
@@ -88,15 +91,13 @@ __global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const A
 #define KZV_ASTAMP() do {} while (0)
 #endif
     KZV_ASTAMP();
-    const bf16_t* Kb = p.K + (int64_t)b * p.Sk * p.ldk + h * 64;
-    const bf16_t* Vb = p.V + (int64_t)b * p.Sk * p.ldv + h * 64;
-    stage_image<SP, 4>(Ks, Kb, p.ldk, p.Sk, p.zero16, w, lane);
-    stage_image<SP, 4>(Vs, Vb, p.ldv, p.Sk, p.zero16, w, lane);
-    for (int i = tid; i < SP; i += 256) kvalid[i] = i < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + i] != p.pad_id);
+    stage_image<SPK, 4>(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image<SPV, 4>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    if (MODE == 1)
+        for (int i = tid; i < SPK; i += 256) kvalid[i] = i < p.Sk && p.ids[(int64_t)b * p.ld_ids + i] != p.pad_id;
     // every query fragment this wave will need, requested while the K/V images are still in flight (one exposed
     // memory latency per workgroup instead of one per query tile)
-    constexpr int QI = (KT + 3) / 4;
-    const int nkt = (p.Sk + 15) >> 4, nqt = (p.Sq + 15) >> 4;
+    const int nkt = EXACT ? NKT : (p.Sk + 15) >> 4, nqt = (p.Sq + 15) >> 4;
     bf16x8 qf[QI][2];
 #pragma unroll
     for (int it = 0; it < QI; ++it) {
@@ -104,6 +105,17 @@ __global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const A
         const bf16_t* qrow = p.Q + ((int64_t)b * p.Sq + qc) * p.ldq + h * 64 + 8 * g;
         qf[it][0] = *(const bf16x8*)qrow; qf[it][1] = *(const bf16x8*)(qrow + 32);
     }
+    // per-lane LDS offsets: everything below is `constant + immediate`
+    const unsigned kA = l15 * 128 + ((g ^ (l15 & 7)) << 4), kB = l15 * 128 + (((4 + g) ^ (l15 & 7)) << 4);
+    unsigned vT[4];
+    {
+        const int row = 4 * g + (l15 >> 2), hb = (l15 >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vT[dt] = row * 128 + ((((dt * 2 + hb) ^ (row & 7))) << 4) + (l15 & 1) * 8;
+    }
+    const AttDropLane dl = att_drop_lane(l15 & 3, true);
+    const unsigned thrm1x2 = (unsigned)((p.thr16 - 32768 - 1) & 0xffff) * 0x10001u;
+    const unsigned nQ4 = (unsigned)(p.Sq + 3) >> 2, nK4 = (unsigned)(p.Sk + 3) >> 2;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     KZV_ASTAMP();
@@ -116,21 +128,16 @@ __global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const A
         const int q = qt * 16 + l15;
         const bf16x8 q0 = qf[it][0], q1 = qf[it][1];
         const int nk = MODE == 1 ? min(nkt, qt + 1) : nkt;   // causal: key tiles above the diagonal are empty
-        // Unmasked attention (MODE 0) walks ALL KT key tiles of the LDS image (rows past Sk are zero and masked: <= 1 tile
-        // of waste at 161 tokens) so that the tile loops carry no branches; the causal mode skips tiles above the diagonal.
-        // The softmax / dropout arithmetic below is what bounds this kernel (VALU, not MFMA or HBM), so it is kept lean:
-        // masks only where a key can be invalid, the 1/sqrt(d)*log2(e) scale folded into the exponent's FMA, the raw
-        // v_exp_f32, and 1/sum * 1/keep folded into the dropout select.
-        f32x4 s[KT];
+        // S^T tile: key on the accumulator rows (4g + r), query on the lane column
+        f32x4 s[NKT];
         float mx = -INFINITY;                                 // max of the RAW scores (scale > 0 keeps the order)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
             s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (MODE == 0 || kt < nk) {
-                const int krow = kt * 16 + l15;
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, krow, g), q0, s[kt], 0, 0, 0);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Ks, krow, 4 + g), q1, s[kt], 0, 0, 0);
-                if (MODE == 1 || kt >= nkt - 1) {             // unmasked attention: only key tiles from the last valid one on can run past Sk
+            if (EXACT || kt < nk) {
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + kA + kt * 2048), q0, s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + kB + kt * 2048), q1, s[kt], 0, 0, 0);
+                if (MODE == 1 || (EXACT ? kt == NKT - 1 : kt >= nkt - 1)) {      // only the last valid tile can run past Sk
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 16 + 4 * g + r;
@@ -138,8 +145,7 @@ __global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const A
                         s[kt][r] = ok ? s[kt][r] : -INFINITY;
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+                mx = fmax3(mx, fmax3(s[kt][0], s[kt][1], s[kt][2]), s[kt][3]);
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -147,53 +153,49 @@ __global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const A
         const bool dead = mx == -INFINITY;                    // fully masked row -> zeros, LSE = +inf
         const float mref = dead ? 0.f : mx * sc;
         float sum = 0.f;
+        unsigned pw[NKP * 4];                                 // bf16 pairs of the (dropped, un-normalised) probabilities
+        const unsigned xw0 = (((unsigned)(b * p.heads + h) * nQ4 + ((unsigned)q >> 2)) * nK4 + g) * KZV_ATT_GOLD + p.key;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-            if (MODE == 0 || kt < nk) {
+        for (int kt = 0; kt < NKP * 2; ++kt) {
+            if (kt < NKT && (EXACT || kt < nk)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, -mref)); sum += s[kt][r]; }
+                unsigned w01 = pack_bf2(s[kt][0], s[kt][1]), w23 = pack_bf2(s[kt][2], s[kt][3]);
+                if (p.thr16) {
+                    unsigned u01, u23;
+                    att_drop_u(dl, att_mix(xw0 + (unsigned)kt * (4u * KZV_ATT_GOLD)), &u01, &u23);
+                    w01 &= att_keep_mask(u01, thrm1x2); w23 &= att_keep_mask(u23, thrm1x2);
+                }
+                pw[kt * 2] = w01; pw[kt * 2 + 1] = w23;
+            } else {
+                pw[kt * 2] = 0u; pw[kt * 2 + 1] = 0u;
             }
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = dead ? 0.f : 1.f / sum;
         if (p.LSE && g == 0 && q < p.Sq)
             p.LSE[((int64_t)b * p.heads + h) * p.Sq + q] = dead ? INFINITY : (mx * sc + log2f(sum)) * (1.f / LOG2E);
-        // dropout element index = (row of P) * Sk_even + key: the row base is even, so this lane's 4 consecutive keys
-        // are exactly two hash pairs (2 hashes per 4 probabilities instead of 4)
-        const unsigned ebase = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1);
-        const float keepv = inv * p.inv_keep;                 // value of a kept probability's multiplier
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-            if (MODE == 0 || kt < nk) {
-                if (p.thr16) {
-                    const unsigned pr = (ebase + kt * 16 + 4 * g) >> 1;
-                    const unsigned b0 = drop_bits(p.key, pr), b1 = drop_bits(p.key, pr + 1);
-                    s[kt][0] *= (b0 & 0xffffu) >= p.thr16 ? keepv : 0.f; s[kt][1] *= (b0 >> 16) >= p.thr16 ? keepv : 0.f;
-                    s[kt][2] *= (b1 & 0xffffu) >= p.thr16 ? keepv : 0.f; s[kt][3] *= (b1 >> 16) >= p.thr16 ? keepv : 0.f;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-                }
-            }
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kp = 0; kp < KT / 2; ++kp) {
-            if (MODE == 0 || 2 * kp < nk) {
-                const bf16x8 pf = pack8((const float*)&s[2 * kp], (const float*)&s[2 * kp + 1]);
+        for (int kp = 0; kp < NKP; ++kp) {
+            if (EXACT || 2 * kp < nk) {
+                const bf16x8 pf = words8(pw[kp * 4], pw[kp * 4 + 1], pw[kp * 4 + 2], pw[kp * 4 + 3]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 vf = cat8(frag_tr(Vs, kp * 32 + 4 * g, dt * 2, l15), frag_tr(Vs, kp * 32 + 16 + 4 * g, dt * 2, l15));
+                    const bf16x8 vf = cat8(lds_tr16(Vs + vT[dt] + kp * 4096), lds_tr16(Vs + vT[dt] + kp * 4096 + 2048));
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
             }
         }
+        // softmax normalisation and the dropout scale 1 / P(keep) on the 16 outputs (the probabilities above are exp2 values)
+        const float onorm = dead ? 0.f : p.inv_keep / sum;
         if (q < p.Sq) {
             bf16_t* orow = p.O + ((int64_t)b * p.Sq + q) * p.ldo + h * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                *(uint2*)(orow + dt * 16) = make_uint2(pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3]));
+                *(uint2*)(orow + dt * 16) = make_uint2(pack_bf2(o[dt][0] * onorm, o[dt][1] * onorm), pack_bf2(o[dt][2] * onorm, o[dt][3] * onorm));
         }
         KZV_ASTAMP();
     }
@@ -202,9 +204,11 @@ __global__ __launch_bounds__(256, KT <= 12 ? 3 : 2) void attn_fwd_kernel(const A
 // =============================================================================================== backward
 // LDS budget <= 80 KiB so TWO workgroups share a CU (one stages / waits at a barrier while the other computes):
 // K and V images stay resident; Q and dO come in 32-query slabs through a 2-deep ring (the slab of block qb+1
-// is in flight during block qb); dS for the current slab only.
+// is in flight during block qb); dS^T for the current slab only, as a [key][32 queries] image of 64-byte rows.
 constexpr int SLAB = 32 * 128;                  // 32 rows x 64 bf16
-constexpr int bwd_lds_bytes(int KT) { return 2 * (KT * 16 * 128) + 4 * SLAB + 32 * (KT * 32 + 16) + 3 * KT * 16 * 4; }
+constexpr int bwd_lds_bytes(int NKT) {
+    return ((NKT + 1) / 2 * 32) * 128 + NKT * 16 * 128 + 4 * SLAB + ((NKT + 1) / 2 * 32) * 64 + 3 * ((NKT + 1) / 2 * 32) * 4;
+}
 static_assert(bwd_lds_bytes(12) <= 80 * 1024, "attention backward (<= 192 tokens) must fit two workgroups per CU");
 
 // stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces spread over the NW waves
@@ -232,60 +236,94 @@ __device__ __forceinline__ void stage_image_asm(char* img, const bf16_t* src, in
 }
 
 #ifdef KZV_STAMPS
-__device__ unsigned long long kzv_bwd_stamps[64];
-#define KZV_BSTAMP() do { if (blockIdx.x == 771 && threadIdx.x == 0 && bsk < 64) kzv_bwd_stamps[bsk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long kzv_bwd_stamps[128];
+#define KZV_BSTAMP() do { if (blockIdx.x == 771 && threadIdx.x == 0 && bsk < 128) kzv_bwd_stamps[bsk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define KZV_BSTAMP() do {} while (0)
 #endif
-template <int MODE, int KT, int NW>
+template <int MODE, int NKT, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
     [[maybe_unused]] int bsk = 0;
     KZV_BSTAMP();
-    constexpr int SP = KT * 16, IMG = SP * 128, DS_STRIDE = SP * 2 + 16, DS_BYTES = 32 * DS_STRIDE;
-    constexpr int NT = NW * 64, TPW = (KT + NW - 1) / NW, TB = 8 / NW;   // threads, key tiles per wave, dQ tiles per wave
+    constexpr int NKP = (NKT + 1) / 2, SP = NKP * 32;        // rows of the K and dS^T images (zero past the last key tile)
+    constexpr int NT = NW * 64, TPW = (NKT + NW - 1) / NW, TB = 8 / NW;   // threads, key tiles per wave, dQ tiles per wave
     static_assert(TPW <= 3, "dK/dV accumulators of more than 3 key tiles per wave do not fit the register file");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem; char* Vs = smem + IMG;
-    char* Qring = smem + 2 * IMG; char* Oring = Qring + 2 * SLAB;
-    char* dS = Oring + 2 * SLAB;
-    float* lse = (float*)(dS + DS_BYTES);
+    char* Ks = smem; char* Vs = Ks + SP * 128;
+    char* Qring = Vs + NKT * 16 * 128; char* Oring = Qring + 2 * SLAB;
+    char* dST = Oring + 2 * SLAB;                              // [SP keys][32 queries] bf16, 8-byte units swizzled by (key >> 1) & 7
+    float* lse = (float*)(dST + SP * 64);
     float* dlt = lse + SP;
     int* kvalid = (int*)(dlt + SP);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
     const bf16_t* Qb = p.Q + (int64_t)b * p.Sq * p.ldq + h * 64;
     const bf16_t* dOb = p.dO + (int64_t)b * p.Sq * p.ldo + h * 64;
-    stage_image_asm<SP, NW>(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
-    stage_image_asm<SP, NW>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
-    stage_slabs<NW>(Qring, Oring, Qb, dOb, p.ldq, p.ldo, 0, p.Sq, p.zero16, w, lane);
-    for (int row = tid; row < SP; row += NT) {
-        kvalid[row] = row < p.Sk && (MODE == 0 || p.ids[(int64_t)b * p.ld_ids + row] != p.pad_id);
-        float l = INFINITY, d = 0.f;
-        if (row < p.Sq) {
-            l = p.LSE[((int64_t)b * p.heads + h) * p.Sq + row];
-            const bf16_t* orow = p.O + ((int64_t)b * p.Sq + row) * p.ldo + h * 64;
-            const bf16_t* drow = dOb + (int64_t)row * p.ldo;
+    // log-sum-exp (in log2 units) and delta' = rowsum(dO . O) * P(keep) per query row: four lanes per row, 32 bytes each
+    // (1 / P(keep) is taken out of dS and multiplied back into dQ / dK / dV at the very end).  Their loads are issued
+    // FIRST and all at once -- vmcnt retires in order, so behind the image DMAs they would wait for all 46 KiB of them --
+    // and the arithmetic runs while the DMAs fly.
+    constexpr int DR = (SP + NT / 4 - 1) / (NT / 4);          // rows per thread group
+    bf16x8 ov[DR][2], dv8[DR][2];
+    float lv[DR];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const bf16x8 a = *(const bf16x8*)(orow + c * 8), e = *(const bf16x8*)(drow + c * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)a[j]) * bf2f((bf16_t)e[j]);
-            }
-        }
-        lse[row] = l * LOG2E; dlt[row] = d;
+    for (int i = 0; i < DR; ++i) {
+        const int row = min((tid >> 2) + i * (NT / 4), p.Sq - 1);
+        const bf16_t* orow = p.O + ((int64_t)b * p.Sq + row) * p.ldo + h * 64 + (tid & 3) * 16;
+        const bf16_t* drow = dOb + (int64_t)row * p.ldo + (tid & 3) * 16;
+        ov[i][0] = *(const bf16x8*)orow; ov[i][1] = *(const bf16x8*)(orow + 8);
+        dv8[i][0] = *(const bf16x8*)drow; dv8[i][1] = *(const bf16x8*)(drow + 8);
+        lv[i] = p.LSE[((int64_t)b * p.heads + h) * p.Sq + row];
     }
-    for (int i = tid; i < DS_BYTES / 16; i += NT) ((uint4*)dS)[i] = make_uint4(0, 0, 0, 0);   // key columns no wave writes stay 0
+    stage_image_asm<SP, NW>(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image_asm<NKT * 16, NW>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    stage_slabs<NW>(Qring, Oring, Qb, dOb, p.ldq, p.ldo, 0, p.Sq, p.zero16, w, lane);
+    KZV_BSTAMP();
+    const float keep_p = 1.f / p.inv_keep;
+#pragma unroll
+    for (int i = 0; i < DR; ++i) {
+        const int row = (tid >> 2) + i * (NT / 4);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)ov[i][c][j]) * bf2f((bf16_t)dv8[i][c][j]);
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        if ((tid & 3) == 0 && row < SP) {
+            lse[row] = row < p.Sq ? lv[i] * LOG2E : INFINITY;
+            dlt[row] = row < p.Sq ? d * keep_p : 0.f;
+        }
+    }
+    KZV_BSTAMP();
+    if (MODE == 1)
+        for (int row = tid; row < SP; row += NT) kvalid[row] = row < p.Sk && p.ids[(int64_t)b * p.ld_ids + row] != p.pad_id;
+    for (int i = tid; i < SP * 64 / 16; i += NT) ((uint4*)dST)[i] = make_uint4(0, 0, 0, 0);   // key rows no wave writes stay 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     KZV_BSTAMP();
 
-    const int nkt = (p.Sk + 15) >> 4, nqb = (p.Sq + 31) >> 5;
+    const int nkt = EXACT ? NKT : (p.Sk + 15) >> 4, nqb = (p.Sq + 31) >> 5;
     const float sc = p.scale * LOG2E;
     f32x4 dk[TPW][4], dv[TPW][4];
 #pragma unroll
     for (int a = 0; a < TPW; ++a)
 #pragma unroll
         for (int d = 0; d < 4; ++d) { dk[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // per-lane LDS offsets (constant over the whole sweep)
+    const unsigned rA = l15 * 128 + ((g ^ (l15 & 7)) << 4), rB = l15 * 128 + (((4 + g) ^ (l15 & 7)) << 4);   // row fragments
+    unsigned tT[4];                                                                                          // transposed fragments
+    {
+        const int row = 4 * g + (l15 >> 2), hb = (l15 >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) tT[dt] = row * 128 + ((((dt * 2 + hb) ^ (row & 7))) << 4) + (l15 & 1) * 8;
+    }
+    const AttDropLane dl = att_drop_lane(l15 & 3, false);
+    const int thr_s = (int)p.thr16 - 32768;
+    const unsigned nQ4 = (unsigned)(p.Sq + 3) >> 2, nK4 = (unsigned)(p.Sk + 3) >> 2;
+    // pre-mix word of block (q >> 2 = g, k >> 2 = l15 >> 2) of slab 0; + per slab / 16-query half / key tile multiples of GOLD
+    unsigned xslab = (((unsigned)(b * p.heads + h) * nQ4 + g) * nK4 + (l15 >> 2)) * KZV_ATT_GOLD + p.key;
+    const unsigned xstep_t2 = 4u * nK4 * KZV_ATT_GOLD;
 
     for (int qb = 0; qb < nqb; ++qb) {
         const char* Qs = Qring + (qb & 1) * SLAB;
@@ -296,10 +334,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         bf16x8 dOt[4], Qt[4];     // A operands shared by all key tiles of this wave: dO^T and Q^T over the slab
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            dOt[dt] = cat8(frag_tr(Os, 4 * g, dt * 2, l15), frag_tr(Os, 16 + 4 * g, dt * 2, l15));
-            Qt[dt] = cat8(frag_tr(Qs, 4 * g, dt * 2, l15), frag_tr(Qs, 16 + 4 * g, dt * 2, l15));
+            dOt[dt] = cat8(lds_tr16(Os + tT[dt]), lds_tr16(Os + tT[dt] + 2048));
+            Qt[dt] = cat8(lds_tr16(Qs + tT[dt]), lds_tr16(Qs + tT[dt] + 2048));
         }
-        float lq[8], dq8[8];      // log-sum-exp and delta of this lane's 8 query rows: read once per slab, not per key tile
+        KZV_BSTAMP();
+        float lq[8], dq8[8];      // log-sum-exp and delta' of this lane's 8 query rows: read once per slab, not per key tile
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int q = qb * 32 + (r >> 2) * 16 + 4 * g + (r & 3);
@@ -309,60 +348,52 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         for (int a = 0; a < TPW; ++a) {
             const int kt = w + NW * a;
             if (kt >= nkt) continue;
+            const int key = kt * 16 + l15;
+            char* dsrow = dST + key * 64;
+            const int dsz = (key >> 1) & 7;
             if (MODE == 1 && kt * 16 > qb * 32 + 31) {   // key tile entirely above the diagonal: dS = 0
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    *(bf16_t*)(dS + ((r >> 2) * 16 + 4 * g + (r & 3)) * DS_STRIDE + (kt * 16 + l15) * 2) = 0;
+                for (int t2 = 0; t2 < 2; ++t2) *(uint2*)(dsrow + (((t2 * 4 + g) ^ dsz) << 3)) = make_uint2(0u, 0u);
                 continue;
             }
-            const int key = kt * 16 + l15;
-            const bf16x8 k0 = frag_row(Ks, key, g), k1 = frag_row(Ks, key, 4 + g);
-            const bf16x8 v0 = frag_row(Vs, key, g), v1 = frag_row(Vs, key, 4 + g);
-            const bool kok = kvalid[key];
-            float pd[8], ds[8];
+            const bf16x8 k0 = *(const bf16x8*)(Ks + rA + kt * 2048), k1 = *(const bf16x8*)(Ks + rB + kt * 2048);
+            const bf16x8 v0 = *(const bf16x8*)(Vs + rA + kt * 2048), v1 = *(const bf16x8*)(Vs + rB + kt * 2048);
+            // keys past Sk (last tile) / padding keys: -inf as the INITIAL score accumulator (the key sits on the lane, so all
+            // four registers take the same value) makes their probabilities exp2(-inf) = 0 at no cost per element
+            const bool kok = MODE == 1 ? kvalid[key] != 0 : key < p.Sk;
+            const float sinit = kok ? 0.f : -INFINITY;
+            unsigned pdw[4], dsw[4];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                const int qrow = t2 * 16 + l15;
-                f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
-                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, g), k0, S, 0, 0, 0);
-                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Qs, qrow, 4 + g), k1, S, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, g), v0, dP, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row(Os, qrow, 4 + g), v1, dP, 0, 0, 0);
-                // dropout bits: a hash covers the key PAIR (key & ~1, key | 1) of one query row, and this lane's neighbour
-                // (l15 ^ 1) needs the same four (row, pair) hashes: each computes two rows and they swap through DPP
-                unsigned hb[4] = {0u, 0u, 0u, 0u};
-                if (p.thr16) {
-                    const int par = l15 & 1;
-                    unsigned own[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int q = qb * 32 + t2 * 16 + 4 * g + 2 * par + u;
-                        const unsigned e = (unsigned)((b * p.heads + h) * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1) + (unsigned)key;
-                        own[u] = drop_bits(p.key, e >> 1);
-                    }
-                    const unsigned n0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own[0], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own[1], 0xB1, 0xF, 0xF, true);
-                    hb[0] = par ? n0 : own[0]; hb[1] = par ? n1 : own[1];
-                    hb[2] = par ? own[0] : n0; hb[3] = par ? own[1] : n1;
-                }
+                f32x4 S = (f32x4){sinit, sinit, sinit, sinit}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + rA + t2 * 2048), k0, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + rB + t2 * 2048), k1, S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Os + rA + t2 * 2048), v0, dP, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Os + rB + t2 * 2048), v1, dP, 0, 0, 0);
+                unsigned u01 = 0, u23 = 0;
+                if (p.thr16)      // block (q >> 2 = qb * 8 + t2 * 4 + g, key >> 2 = kt * 4 + (l15 >> 2)); this lane's column is key & 3
+                    att_drop_u(dl, att_mix(xslab + (unsigned)t2 * xstep_t2 + (unsigned)kt * (4u * KZV_ATT_GOLD)), &u01, &u23);
+                float pm[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qb * 32 + t2 * 16 + 4 * g + r;
-                    const bool ok = kok && (MODE == 0 || key <= q);
-                    float pr = ok ? __builtin_amdgcn_exp2f(S[r] * sc - lq[t2 * 4 + r]) : 0.f;      // lse = +inf for q >= Sq / dead rows
-                    float kp = 1.f;
-                    if (p.thr16) kp = drop_keep(hb[r], key & 1, p.thr16, p.inv_keep);
-                    pd[t2 * 4 + r] = pr * kp;
-                    ds[t2 * 4 + r] = pr * (dP[r] * kp - dq8[t2 * 4 + r]);
-                    *(bf16_t*)(dS + (t2 * 16 + 4 * g + r) * DS_STRIDE + key * 2) = f2bf(ds[t2 * 4 + r]);
+                    float pr = __builtin_amdgcn_exp2f(fmaf(S[r], sc, -lq[t2 * 4 + r]));      // lse = +inf for q >= Sq / dead rows
+                    if (MODE == 1) pr = key <= qb * 32 + t2 * 16 + 4 * g + r ? pr : 0.f;     // causal
+                    const unsigned ur = (r & 2) ? u23 : u01;
+                    const int us = (r & 1) ? (int)ur >> 16 : (int)(short)(ur & 0xffffu);
+                    pm[r] = (!p.thr16 || us >= thr_s) ? pr : 0.f;
+                    ds[r] = fmaf(pm[r], dP[r], -pr * dq8[t2 * 4 + r]);
                 }
+                pdw[t2 * 2] = pack_bf2(pm[0], pm[1]); pdw[t2 * 2 + 1] = pack_bf2(pm[2], pm[3]);
+                dsw[t2 * 2] = pack_bf2(ds[0], ds[1]); dsw[t2 * 2 + 1] = pack_bf2(ds[2], ds[3]);
+                *(uint2*)(dsrow + (((t2 * 4 + g) ^ dsz) << 3)) = make_uint2(dsw[t2 * 2], dsw[t2 * 2 + 1]);
             }
-            const bf16x8 pf = pack8(pd, pd + 4), df = pack8(ds, ds + 4);
+            const bf16x8 pf = words8(pdw[0], pdw[1], pdw[2], pdw[3]), df = words8(dsw[0], dsw[1], dsw[2], dsw[3]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 dv[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOt[dt], pf, dv[a][dt], 0, 0, 0);
                 dk[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt[dt], df, dk[a][dt], 0, 0, 0);
             }
+            KZV_BSTAMP();
         }
         KZV_BSTAMP();
         __syncthreads();
@@ -370,38 +401,53 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         // ---------------- phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for this 32-query slab ----
         {
             const int t2 = w / (NW / 2), dt0 = (w % (NW / 2)) * TB;
-            const int qloc = t2 * 16 + l15;
-            const int q = qb * 32 + qloc;
+            const int q = qb * 32 + t2 * 16 + l15;
             f32x4 acc[TB];
 #pragma unroll
             for (int u = 0; u < TB; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int nks = (nkt + 1) >> 1;
-            for (int ks = 0; ks < nks; ++ks) {
-                const bf16x8 dsf = *(const bf16x8*)(dS + qloc * DS_STRIDE + (ks * 32 + 8 * g) * 2);
+            // this lane's piece of a transposed dS^T read: key row 8g + (l15 >> 2) (+4), the 4 queries of unit t2 * 4 + (l15 & 3)
+            const int krow = 8 * g + (l15 >> 2);
+            const unsigned dA = krow * 64 + (((t2 * 4 + (l15 & 3)) ^ ((krow >> 1) & 7)) << 3);
+            const unsigned dB = (krow + 4) * 64 + (((t2 * 4 + (l15 & 3)) ^ (((krow + 4) >> 1) & 7)) << 3);
+            unsigned kT[TB][2];
 #pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    const int dt = dt0 + u;
-                    const bf16x8 kf = cat8(frag_tr(Ks, ks * 32 + 8 * g, dt * 2, l15), frag_tr(Ks, ks * 32 + 8 * g + 4, dt * 2, l15));
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[u], 0, 0, 0);
+            for (int u = 0; u < TB; ++u) {
+                const int row = 8 * g + (l15 >> 2), chunk = (dt0 + u) * 2 + ((l15 >> 1) & 1);
+                kT[u][0] = row * 128 + ((chunk ^ (row & 7)) << 4) + (l15 & 1) * 8;
+                kT[u][1] = (row + 4) * 128 + ((chunk ^ ((row + 4) & 7)) << 4) + (l15 & 1) * 8;
+            }
+            const int nks = EXACT ? NKP : (nkt + 1) >> 1;
+#pragma unroll
+            for (int ks = 0; ks < NKP; ++ks) {
+                if (EXACT || ks < nks) {
+                    const bf16x8 dsf = cat8(lds_tr16(dST + dA + ks * 2048), lds_tr16(dST + dB + ks * 2048));
+#pragma unroll
+                    for (int u = 0; u < TB; ++u) {
+                        const bf16x8 kf = cat8(lds_tr16(Ks + kT[u][0] + ks * 4096), lds_tr16(Ks + kT[u][1] + ks * 4096));
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, acc[u], 0, 0, 0);
+                    }
                 }
             }
+            KZV_BSTAMP();
             // The next slab (this wave's pieces, issued a whole block ago) has landed.  The wait sits BEFORE the dQ
             // stores: vmcnt retires in issue order, so after them it would also wait for stores issued a moment ago.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (q < p.Sq) {
+                const float osc = p.scale * p.inv_keep;
                 bf16_t* row = p.dQ + ((int64_t)b * p.Sq + q) * p.ldq + h * 64 + 4 * g;
 #pragma unroll
                 for (int u = 0; u < TB; ++u) {
                     const int dt = dt0 + u;
-                    *(uint2*)(row + dt * 16) = make_uint2(pack_bf2(acc[u][0] * p.scale, acc[u][1] * p.scale),
-                                                          pack_bf2(acc[u][2] * p.scale, acc[u][3] * p.scale));
+                    *(uint2*)(row + dt * 16) = make_uint2(pack_bf2(acc[u][0] * osc, acc[u][1] * osc), pack_bf2(acc[u][2] * osc, acc[u][3] * osc));
                 }
             }
         }
+        xslab += 2u * xstep_t2;
         KZV_BSTAMP();
-        __syncthreads();          // publishes everyone's slab pieces and frees dS
+        __syncthreads();          // publishes everyone's slab pieces and frees dS^T
         KZV_BSTAMP();
     }
+    const float ksc = p.scale * p.inv_keep;
 #pragma unroll
     for (int a = 0; a < TPW; ++a) {
         const int key = (w + NW * a) * 16 + l15;
@@ -410,9 +456,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         bf16_t* vrow = p.dV + ((int64_t)b * p.Sk + key) * p.ldv + h * 64 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            *(uint2*)(krow + dt * 16) = make_uint2(pack_bf2(dk[a][dt][0] * p.scale, dk[a][dt][1] * p.scale),
-                                                   pack_bf2(dk[a][dt][2] * p.scale, dk[a][dt][3] * p.scale));
-            *(uint2*)(vrow + dt * 16) = make_uint2(pack_bf2(dv[a][dt][0], dv[a][dt][1]), pack_bf2(dv[a][dt][2], dv[a][dt][3]));
+            *(uint2*)(krow + dt * 16) = make_uint2(pack_bf2(dk[a][dt][0] * ksc, dk[a][dt][1] * ksc), pack_bf2(dk[a][dt][2] * ksc, dk[a][dt][3] * ksc));
+            *(uint2*)(vrow + dt * 16) = make_uint2(pack_bf2(dv[a][dt][0] * p.inv_keep, dv[a][dt][1] * p.inv_keep),
+                                                   pack_bf2(dv[a][dt][2] * p.inv_keep, dv[a][dt][3] * p.inv_keep));
         }
     }
 }
@@ -441,12 +487,26 @@ int fill(AttnP& p, const kzv_attn_args* a, bool bwd) {
 }  // namespace
 
 #ifdef KZV_STAMPS
-extern "C" int kzv_debug_bwd_stamps(unsigned long long* host64) {
-    return hipMemcpyFromSymbol(host64, HIP_SYMBOL(kzv_bwd_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+extern "C" int kzv_debug_bwd_stamps(unsigned long long* host128) {
+    return hipMemcpyFromSymbol(host128, HIP_SYMBOL(kzv_bwd_stamps), 128 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 
 int kzv_attn_generic(const kzv_attn_args* a, int D, bool bwd, hipStream_t s);      // attention_generic.hip
+
+template <int MODE, int NKT, bool EXACT>
+static void launch_fwd(const AttnP& p, int blocks, hipStream_t s) {
+    constexpr int lds = (NKT * 16 + (NKT + 1) / 2 * 32) * 128 + NKT * 16 * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<MODE, NKT, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<MODE, NKT, EXACT>), dim3(blocks), dim3(256), lds, s, p);
+}
+template <int MODE, int NKT, int NW, bool EXACT>
+static void launch_bwd(const AttnP& p, int blocks, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<MODE, NKT, NW, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(NKT)); attr = true; }
+    hipLaunchKernelGGL((attn_bwd_kernel<MODE, NKT, NW, EXACT>), dim3(blocks), dim3(NW * 64), bwd_lds_bytes(NKT), s, p);
+}
 
 extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
     if (a && a->head_dim != 0 && a->head_dim != 64) {
@@ -458,15 +518,14 @@ extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
     AttnP p;
     if (int rc = fill(p, a, false)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const bool big = a->Sq > 192 || a->Sk > 192;
-    const int lds = big ? 2 * (288 * 128) + 288 * 4 : 2 * (192 * 128) + 192 * 4;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<0, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (288 * 128) + 288 * 4); attr = true; }
+    const int nkt = (a->Sk + 15) >> 4, nqt = (a->Sq + 15) >> 4, blocks = a->B * a->heads;
     KzvProfScope prof(2, 4.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
-    const dim3 grid(a->B * a->heads);
-    if (a->mode == 1) hipLaunchKernelGGL((attn_fwd_kernel<1, 12>), grid, dim3(256), lds, s, p);
-    else if (big) hipLaunchKernelGGL((attn_fwd_kernel<0, 18>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<0, 12>), grid, dim3(256), lds, s, p);
+    // exact-tile instances for the two hot shapes (a wave holds ceil(NKT / 4) query tiles: 12 for both)
+    if (a->mode == 1) launch_fwd<1, 12, false>(p, blocks, s);
+    else if (nkt == 11 && nqt <= 12) launch_fwd<0, 11, true>(p, blocks, s);
+    else if (nkt == 10 && nqt <= 12) launch_fwd<0, 10, true>(p, blocks, s);
+    else if (nkt <= 12 && nqt <= 12) launch_fwd<0, 12, false>(p, blocks, s);
+    else launch_fwd<0, 18, false>(p, blocks, s);
     return kzv_check_launch("attn_fwd");
 }
 
@@ -480,18 +539,13 @@ extern "C" int kzv_attn_bwd(const kzv_attn_args* a, void* stream) {
     AttnP p;
     if (int rc = fill(p, a, true)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(12));
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1, 12, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(12));
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0, 18, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(18));
-        attr = true;
-    }
-    const bool big = a->Sq > 192 || a->Sk > 192;
+    const int nkt = (a->Sk + 15) >> 4, nqb = (a->Sq + 31) >> 5, blocks = a->B * a->heads;
     KzvProfScope prof(3, 10.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
-    const dim3 grid(a->B * a->heads);
-    if (a->mode == 1) hipLaunchKernelGGL((attn_bwd_kernel<1, 12, 4>), grid, dim3(256), bwd_lds_bytes(12), s, p);
-    else if (big) hipLaunchKernelGGL((attn_bwd_kernel<0, 18, 8>), grid, dim3(512), bwd_lds_bytes(18), s, p);
-    else hipLaunchKernelGGL((attn_bwd_kernel<0, 12, 4>), grid, dim3(256), bwd_lds_bytes(12), s, p);
+    // the per-row arrays (log-sum-exp, delta) hold 32 * ceil(NKT / 2) queries: 192 for every <= 12-tile instance
+    if (a->mode == 1) launch_bwd<1, 12, 4, false>(p, blocks, s);
+    else if (nkt == 11 && nqb <= 6) launch_bwd<0, 11, 4, true>(p, blocks, s);
+    else if (nkt == 10 && nqb <= 5) launch_bwd<0, 10, 4, true>(p, blocks, s);
+    else if (nkt <= 12 && nqb <= 6) launch_bwd<0, 12, 4, false>(p, blocks, s);
+    else launch_bwd<0, 18, 8, false>(p, blocks, s);
     return kzv_check_launch("attn_bwd");
 }

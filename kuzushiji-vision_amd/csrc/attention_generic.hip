@@ -33,8 +33,9 @@ constexpr int QT = 16;       // queries (or keys, kernel B) per workgroup
 
 __device__ __forceinline__ float keep_mul(const GenP& p, int pair, int q, int k) {
     if (!p.thr16) return 1.f;
-    const unsigned e = (unsigned)(pair * p.Sq + q) * (unsigned)((p.Sk + 1) & ~1) + (unsigned)k;     // attention.hip's element index
-    return drop_keep(drop_bits(p.key, e >> 1), e & 1, p.thr16, p.inv_keep);
+    // the attention sites' 4 x 4-block generator (kzv_common.h), scalar form: same masks as attention.hip would draw
+    const unsigned block = ((unsigned)pair * ((unsigned)(p.Sq + 3) >> 2) + ((unsigned)q >> 2)) * ((unsigned)(p.Sk + 3) >> 2) + ((unsigned)k >> 2);
+    return att_keep1(p.key, block, q & 3, k & 3, (int)p.thr16) ? p.inv_keep : 0.f;
 }
 
 // stage rows [0, n) of a [n, D] bf16 matrix (row stride ld) into LDS rows of stride DP = D + 2 elements

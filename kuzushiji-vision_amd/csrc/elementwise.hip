@@ -363,6 +363,17 @@ __global__ void dropout_mask_kernel(float* __restrict__ out, int64_t rows, int64
     out[t] = thr16 ? drop_keep(drop_bits(key, e >> 1), e & 1, thr16, inv_keep) : 1.f;
 }
 
+// same for an attention-probability site: rows = (batch * heads + head) * Sq + q, the 4 x 4-block generator of kzv_common.h
+__global__ void attn_dropout_mask_kernel(float* __restrict__ out, int64_t pairs, int Sq, int Sk, unsigned thr16, float inv_keep, unsigned key) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pairs * Sq * Sk) return;
+    const int64_t row = t / Sk;
+    const int k = (int)(t - row * Sk), q = (int)(row % Sq);
+    const unsigned pair = (unsigned)(row / Sq);
+    const unsigned block = (pair * ((unsigned)(Sq + 3) >> 2) + ((unsigned)q >> 2)) * ((unsigned)(Sk + 3) >> 2) + ((unsigned)k >> 2);
+    out[t] = !thr16 ? 1.f : att_keep1(key, block, q & 3, k & 3, (int)thr16) ? inv_keep : 0.f;
+}
+
 inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 }  // namespace
@@ -462,6 +473,14 @@ int kzv_fp8_roll(float* qscale, float* amax, float* row_scales, int sites, int r
     hipLaunchKernelGGL(fp8_roll_kernel, dim3(nblk(rows, 256) < 64 ? nblk(rows, 256) : 64, sites), dim3(256), 0, s, qscale, amax, row_scales, sites, rows);
     hipLaunchKernelGGL(fp8_roll_publish_kernel, dim3(nblk(sites, 64)), dim3(64), 0, s, qscale, amax, sites);
     return kzv_check_launch("fp8_roll");
+}
+
+extern "C" int kzv_debug_attn_dropout_mask(uint32_t key, float p, int64_t pairs, int32_t Sq, int32_t Sk, float* d_out, void* stream) {
+    if (!d_out || pairs < 0 || Sq <= 0 || Sk <= 0) return kzv_fail(KZV_E_ARG, "debug_attn_dropout_mask: bad shape");
+    if (pairs == 0) return KZV_OK;
+    unsigned thr; float ik; kzv_drop_params(p, &thr, &ik);
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(nblk(pairs * Sq * Sk, 256)), dim3(256), 0, (hipStream_t)stream, d_out, pairs, Sq, Sk, thr, ik, key);
+    return kzv_check_launch("debug_attn_dropout_mask");
 }
 
 extern "C" int kzv_debug_dropout_mask(uint32_t key, float p, int64_t rows, int64_t cols, int64_t ld_index, float* d_out, void* stream) {

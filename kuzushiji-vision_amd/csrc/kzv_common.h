@@ -65,6 +65,59 @@ __device__ __forceinline__ float drop_keep(unsigned bits, int which, unsigned th
     return r >= thr16 ? inv_keep : 0.f;
 }
 
+// ---- attention-probability dropout: 4 x 4 blocks of one (batch, head)'s [Sq, Sk] matrix ---------------------------
+// The forward kernel holds 4 consecutive KEYS of one query per lane, the backward kernel 4 consecutive QUERIES of one key,
+// so the generator is built to cost the same in either orientation: ONE 32-bit hash per 4 x 4 block
+//     x = mix(block * 0x9E3779B9 + key),   block = ((b * heads + h) * ceil(Sq / 4) + (q >> 2)) * ceil(Sk / 4) + (k >> 2)
+// and per element (r = q & 3, c = k & 3) a 16-bit value from one 16-bit half of x (low half if r + c is even):
+//     u = ((half ^ C[r][c]) * M[r][c]) mod 2^16        kept iff (int16) u >= thr16 - 32768      (P(drop) = thr16 / 65536)
+// A lane computes its 4 elements as two packed pairs (v_pk_mul_lo_u16): ~3.5 VALU slots per element against ~6.5 for the
+// 32-bit hash per key pair of the hidden-state sites.  C / M were picked (tools/dev/pick_attn_drop_consts.py) so that the
+// joint drop rates of the 8 elements sharing a half stay within sampling noise of independence over all 2^16 halves;
+// oracle/attn_dropout.py is the numpy statement, pinned bit-for-bit against kzv_debug_attn_dropout_mask on the GPU.
+#define KZV_ATT_GOLD 0x9E3779B9U
+__device__ __constant__ const unsigned short kzv_att_c[16] = {0xba79, 0x0e76, 0x9b89, 0x53b0, 0x431d, 0x0cc3, 0xa452, 0x4805,
+                                                              0xd3bc, 0xd36a, 0x9c49, 0x9be5, 0xd12f, 0x8ff4, 0x38f5, 0x7f7a};
+__device__ __constant__ const unsigned short kzv_att_m[16] = {0x5195, 0x0735, 0xf067, 0x26fb, 0xbafb, 0xee95, 0xe455, 0x0e9d,
+                                                              0x1f77, 0xc189, 0x6fa9, 0x4599, 0x31b9, 0x473d, 0xf055, 0xa1a9};
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+__device__ __forceinline__ unsigned att_mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; return x; }
+// scalar form (one element): the generic head-dim kernels and the debug / parity entry
+__device__ __forceinline__ bool att_keep1(unsigned key, unsigned block, int r, int c, int thr16) {
+    const unsigned x = att_mix(block * KZV_ATT_GOLD + key);
+    const unsigned half = ((r + c) & 1) ? (x >> 16) : (x & 0xffffu);
+    const unsigned u = ((half ^ kzv_att_c[r * 4 + c]) * kzv_att_m[r * 4 + c]) & 0xffffu;
+    return (int)(short)u >= thr16 - 32768;
+}
+// packed form: per-lane constants for the lane's FIXED in-block index (forward: r = q & 3, elements run along c;
+// backward: c = key & 3, elements run along r)
+struct AttDropLane { unsigned c01, c23, m01, m23, rot; };
+__device__ __forceinline__ AttDropLane att_drop_lane(int fixed, bool along_c) {
+    unsigned cc[4], mm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = along_c ? fixed * 4 + j : j * 4 + fixed;
+        cc[j] = kzv_att_c[idx]; mm[j] = kzv_att_m[idx];
+    }
+    AttDropLane d;
+    d.c01 = cc[0] | (cc[1] << 16); d.c23 = cc[2] | (cc[3] << 16);
+    d.m01 = mm[0] | (mm[1] << 16); d.m23 = mm[2] | (mm[3] << 16);
+    d.rot = (fixed & 1) ? 16u : 0u;      // odd fixed index: element 0 takes the HIGH half of x
+    return d;
+}
+// the lane's four 16-bit values as two packed pairs (elements 0,1 | 2,3) from the mixed block word
+__device__ __forceinline__ void att_drop_u(const AttDropLane& d, unsigned xmixed, unsigned* u01, unsigned* u23) {
+    const unsigned xr = __builtin_amdgcn_alignbit(xmixed, xmixed, d.rot);
+    *u01 = __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, xr ^ d.c01) * __builtin_bit_cast(u16x2_t, d.m01));
+    *u23 = __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2_t, xr ^ d.c23) * __builtin_bit_cast(u16x2_t, d.m23));
+}
+// 0xffff per kept element, 0 per dropped one; thrm1x2 = two copies of (int16)(thr16 - 32768 - 1)
+__device__ __forceinline__ unsigned att_keep_mask(unsigned u2, unsigned thrm1x2) {
+    const i16x2_t t = __builtin_elementwise_sub_sat(__builtin_bit_cast(i16x2_t, thrm1x2), __builtin_bit_cast(i16x2_t, u2));
+    return __builtin_bit_cast(unsigned, t >> 15);
+}
+
 // erf-GELU and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7 before fp32 rounding):
 // one v_rcp, one v_exp and 6 FMAs instead of libm's erff (~60 VALU ops), which made the GEMM epilogues
 // VALU-bound.  The Gaussian the derivative needs is the same exponential (exp(-(x/sqrt2)^2) = exp(-x^2/2)).

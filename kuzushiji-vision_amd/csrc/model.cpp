@@ -797,6 +797,9 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
                 if (hipEventCreateWithFlags(&m->ev_done[i], hipEventDisableTiming) != hipSuccess) return kzv_fail(KZV_E_HIP, "model_bind: event");
         }
     }
+    // a captured decode step holds pointers INTO the workspace and the parameter buffer: none survives a rebind
+    for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
+    m->ckv_dec_ok = false;
     m->bound = true; m->have_fwd = false; m->have_enc = false;
     return KZV_OK;
 }

@@ -130,6 +130,7 @@ SYMBOLS = {
     "kzv_attn_bwd": (C.c_int, [C.POINTER(kzv_attn_args), _P]),
     "kzv_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "kzv_debug_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "kzv_debug_attn_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "kzv_prof_select": (C.c_int, [C.c_uint]),
     "kzv_prof_sample": (C.c_int, [C.c_int]),

@@ -107,12 +107,15 @@ def build_checkpoint(cfg, flat_params, hparams: dict, epoch: int, global_step: i
     return ck
 
 
+_HF_BUFFERS = ("position_ids", "token_type_ids")      # HF registered buffers (persistent in some transformers versions)
+
+
 def parameter_names_of(state_dict) -> list[str]:
     """Parameter order of a LOADED reference checkpoint: its state_dict keys in order, shared storages once (the first
     name wins, as ``named_parameters`` does), registered buffers dropped."""
     seen, out = set(), []
     for k, v in state_dict.items():
-        if k.endswith(("position_ids", "token_type_ids")):       # HF registered buffers (persistent in some versions)
+        if k.endswith(_HF_BUFFERS):
             continue
         key = (v.untyped_storage().data_ptr(), v.storage_offset(), tuple(v.shape)) if hasattr(v, "untyped_storage") else id(v)
         if key in seen:
@@ -126,10 +129,14 @@ def read_checkpoint(ck: dict, cfg):
     """-> (state_dict under canonical names, optimizer dict in kzv.optim layout or None).  Accepts either ViT spelling;
     the optimizer state is mapped through the checkpoint's OWN parameter order."""
     import torch
-    sd = {P.canonical_hf_name(k): v for k, v in ck["state_dict"].items()}
+    # HF registered buffers (persisted by some transformers versions) are not parameters: same filter as parameter_names_of
+    sd = {P.canonical_hf_name(k): v for k, v in ck["state_dict"].items() if not k.endswith(_HF_BUFFERS)}
     opt = None
     if ck.get("optimizer_states"):
         osd = ck["optimizer_states"][0]
+        if "state" not in osd or "param_groups" not in osd:
+            raise ValueError("optimizer_states[0] is not in schedulefree's {'state', 'param_groups'} layout (checkpoints written by "
+                             "this engine before round 2 used a flat layout that is no longer loadable: re-save from the weights)")
         names = [P.canonical_hf_name(k) for k in parameter_names_of(ck["state_dict"])]
         if len(names) != len(osd["state"]):
             raise ValueError(f"optimizer state has {len(osd['state'])} entries, the state_dict {len(names)} parameters")

@@ -195,8 +195,19 @@ class TrOCRModel:
     def to(self, device):
         return self
 
-    def log(self, name, value, **kw):
-        self.logged.setdefault(name, []).append(float(value))
+    def log(self, name, value, sync_dist: bool = False, **kw):
+        """LightningModule.log: the reference logs train_loss / val_loss / val_cer / test_* WITHOUT sync_dist
+        (trocr_model.py:331,342,358,370,388), i.e. each rank's own value and rank 0's in the logger -- the default here.
+        sync_dist=True is Lightning's mean over ranks: one scalar all-reduce."""
+        v = float(value)
+        if sync_dist:
+            import torch
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                t = torch.tensor([v], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                v = float(t.item()) / dist.get_world_size()
+        self.logged.setdefault(name, []).append(v)
 
     def optimizers(self):
         return self._optimizer
@@ -347,13 +358,14 @@ class TrOCRModel:
                 L.check(lib.kzv_decode_reorder(self._h, rows.data_ptr(), n_keys, L.stream_handle()), "decode_reorder")
 
         topk = update = None
-        if nb > 1 and nb <= 8 and self.device.type == "cuda" and os.environ.get("KZV_BEAM_TOPK", "1") != "0":
-            topk, update = BM.make_device_hooks(B, nb, Lh, c.vocab, c.eos_id, early_stopping, length_penalty, self.device)
-            if os.environ.get("KZV_BEAM_UPDATE", "1") == "0":
-                update = None
 
         try:
             with torch.cuda.stream(side):
+                # the hooks allocate and zero their flag / top-k buffers: on the stream whose kernels read them
+                if nb > 1 and nb <= 8 and self.device.type == "cuda" and os.environ.get("KZV_BEAM_TOPK", "1") != "0":
+                    topk, update = BM.make_device_hooks(B, nb, Lh, c.vocab, c.eos_id, early_stopping, length_penalty, self.device)
+                    if os.environ.get("KZV_BEAM_UPDATE", "1") == "0":
+                        update = None
                 if use_cache:
                     L.check(lib.kzv_set_active_length(self._h, 1), "set_active_length")
                     L.check(lib.kzv_decode_begin(self._h, L.stream_handle()), "decode_begin")

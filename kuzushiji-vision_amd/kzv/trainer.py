@@ -22,8 +22,13 @@ def dist_env():
     return rank, world, local
 
 
+def dp_forced() -> bool:
+    """Rehearsal switch: run the world > 1 code path (init_distributed, Stepper.step) with whatever world size there is."""
+    return os.environ.get("KZV_FORCE_DIST", "0") not in ("", "0")
+
+
 def init_distributed(backend: str | None = None):
-    """torch.distributed over RCCL ("nccl" on ROCm) for GPUs, gloo on CPU.  No-op for world size 1."""
+    """torch.distributed over RCCL ("nccl" on ROCm) for GPUs, gloo on CPU.  No-op for world size 1 (unless KZV_FORCE_DIST)."""
     import torch
     import torch.distributed as dist
     rank, world, local = dist_env()
@@ -31,7 +36,9 @@ def init_distributed(backend: str | None = None):
     if os.environ.get("KZV_FORCE_DEVICE") is not None:
         local = int(os.environ["KZV_FORCE_DEVICE"])
     backend = backend or os.environ.get("KZV_DIST_BACKEND")
-    if world > 1 and not dist.is_initialized():
+    # KZV_FORCE_DIST=1: build the process group even for ONE rank, so that a 1-GPU box executes the data-parallel branch
+    # end to end (RCCL communicator on the device, async all-reduce on RCCL's stream, CU reserve, segmented backward)
+    if (world > 1 or dp_forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend is None:
@@ -74,8 +81,11 @@ class Stepper:
     """One training step of the hot path: forward+loss, segmented backward with overlapped bucketed
     all-reduce, clip, RAdamScheduleFree step, bf16 weight refresh."""
 
-    def __init__(self, model, optimizer, world: int = 1, max_grad_norm: float = 1.0, bucket_mb: float = 64.0):
+    def __init__(self, model, optimizer, world: int = 1, max_grad_norm: float = 1.0, bucket_mb: float = 64.0,
+                 dp_path: bool | None = None):
         self.model, self.opt, self.world, self.max_grad_norm = model, optimizer, world, max_grad_norm
+        # the data-parallel branch of step(); with one rank it is a rehearsal (a 1-rank all-reduce is the identity)
+        self.dp_path = (world > 1 or dp_forced()) if dp_path is None else bool(dp_path)
         lib = L.load()
         n = lib.kzv_backward_segments(model._h)
         self.seg_ranges = []
@@ -93,7 +103,7 @@ class Stepper:
         st = L.stream_handle()
         L.check(lib.kzv_zero_grads(m._h, st), "zero_grads")
         works = []
-        if self.world == 1:      # no consumer between segments: let the engine overlap across them
+        if not self.dp_path:     # no consumer between segments: let the engine overlap across them
             L.check(lib.kzv_backward(m._h, st), "backward")
             self.opt.step(max_grad_norm=self.max_grad_norm, grad_scale=1.0)
             return loss
@@ -101,7 +111,7 @@ class Stepper:
         bi = 0
         for s in range(len(self.seg_ranges)):
             L.check(lib.kzv_backward_segment(m._h, s, st), "backward_segment")
-            if self.world > 1 and s == self.buckets[bi][0]:
+            if s == self.buckets[bi][0]:
                 _, lo, hi = self.buckets[bi]
                 # async: RCCL waits for the kernels enqueued so far on this stream, then runs on its own
                 # stream while the remaining backward segments keep the compute stream busy

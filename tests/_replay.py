@@ -38,9 +38,12 @@ def step_masks(cfg, seed: int, B: int, T: int) -> dict[str, torch.Tensor]:
         if p > 0:
             m[name] = _mask(seed, site, p, rows, cols).reshape(shape).cpu()
 
-    def probs(name, site, p, heads, sq, sk):
+    def probs(name, site, p, heads, sq, sk):       # attention-probability sites: the 4 x 4-block generator
         if p > 0:
-            m[name] = _mask(seed, site, p, B * heads * sq, sk, (sk + 1) & ~1).reshape(B, heads, sq, sk).cpu()
+            lib = L.load()
+            out = torch.empty(B * heads * sq, sk, dtype=torch.float32, device="cuda")
+            L.check(lib.kzv_debug_attn_dropout_mask(lib.kzv_drop_key(seed, site), p, B * heads, sq, sk, out.data_ptr(), L.stream_handle()), "attn mask")
+            m[name] = out.reshape(B, heads, sq, sk).cpu()
 
     hidden("enc_emb", SITE_ENC_EMB, cfg.enc_hidden_dropout, B * Se, He, (B, Se, He))
     for i in range(cfg.enc_layers):

@@ -1,6 +1,7 @@
 """Worker of tests/test_configs_gpu.py::test_two_rank_stepper_on_one_gpu: one rank of a data-parallel run of the REAL
 kzv.trainer.Stepper (segmented backward, bucketed async all-reduce, clip after the reduce, optimizer) -- several ranks
-share GPU 0 and talk over gloo (KZV_DIST_BACKEND=gloo KZV_FORCE_DEVICE=0), because a dev box has one GPU."""
+share GPU 0 and talk over gloo (KZV_DIST_BACKEND=gloo KZV_FORCE_DEVICE=0), because a dev box has one GPU.  With WORLD_SIZE=1
+and KZV_FORCE_DIST=1 the same worker is the one-rank RCCL rehearsal (test_one_rank_rccl_rehearsal_of_the_dp_branch)."""
 import os
 import sys
 
@@ -46,9 +47,15 @@ def main():
         st.step(shard_batch(cfg, step, rank, world, PER_RANK), step)
         norms.append(opt.grad_norm())
     torch.cuda.synchronize()
-    torch.save({"params": m.flat_params.cpu(), "norms": norms, "buckets": st.buckets}, os.path.join(out, f"rank{rank}.pt"))
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+    m.logged.clear()
+    m.log("rank_value", float(rank + 1), sync_dist=True)          # Lightning's sync_dist: mean over ranks (C2)
+    import torch.distributed as dist
+    torch.save({"params": m.flat_params.cpu(), "norms": norms, "buckets": st.buckets, "synced": m.logged["rank_value"][0],
+                "backend": dist.get_backend() if dist.is_initialized() else None, "dp_path": st.dp_path,
+                "nchannels": os.environ.get("NCCL_MAX_NCHANNELS")}, os.path.join(out, f"rank{rank}.pt"))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

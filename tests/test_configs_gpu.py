@@ -136,6 +136,7 @@ def test_two_rank_stepper_on_one_gpu(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert r0["synced"] == r1["synced"] == 1.5                # log(..., sync_dist=True): mean of the ranks' values (C2)
     assert torch.equal(r0["params"], r1["params"])            # identical gradients after the reduce -> identical replicas
     assert r0["norms"] == r1["norms"]                         # the clip saw the same (reduced) gradient on both ranks
     # single process: per-rank gradients averaged by hand, then clip + step on the averaged gradient
@@ -156,16 +157,54 @@ def test_two_rank_stepper_on_one_gpu(tmp_path):
     torch.cuda.synchronize()
     mine, theirs = P.state_dict_from_flat(cfg, m.flat_params.cpu().numpy()), P.state_dict_from_flat(cfg, r0["params"].numpy())
     init = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 4))
-    moved = 0.0
+    moved = worst = 0.0
     for k in mine:
         if k.endswith("key.bias"):      # exactly-zero true gradient: Adam normalises float-atomic noise there
             continue
         step_k = float(np.abs(mine[k] - init[k].reshape(mine[k].shape)).max())       # how far the optimizer moved this tensor
         # the two runs differ by float-atomic summation order in the gradients; Adam's normalisation turns that into a
         # small fraction of the update (elements whose gradient sits near the rounding floor): compare against the update
-        assert np.abs(mine[k] - theirs[k]).max() < 0.05 * step_k + 1e-7, (k, step_k)
+        ratio = float(np.abs(mine[k] - theirs[k]).max()) / (step_k + 1e-12)
+        worst = max(worst, ratio if step_k > 1e-6 else 0.0)
+        assert np.abs(mine[k] - theirs[k]).max() < 0.02 * step_k + 1e-7, (k, step_k, ratio)
         moved = max(moved, step_k)
+    print(f"two-rank vs hand-averaged: worst |difference| / |update| over tensors = {worst:.4f}")
     assert moved > 1e-3                   # the steps after the optimizer's silent phase moved the parameters
+
+
+def test_one_rank_rccl_rehearsal_of_the_dp_branch(tmp_path):
+    """The data-parallel branch on RCCL itself (what Lightning's implicit DDP does for scripts/train_trocr.py:165-176), on the
+    one GPU a dev box has: a fresh child process builds a ONE-rank `nccl` process group (KZV_FORCE_DIST=1) and runs the
+    world > 1 path of Stepper.step -- init_process_group("nccl", device_id=...), NCCL_MAX_NCHANNELS=16, kzv_set_cu_reserve(32),
+    segmented backward, bucketed all_reduce(async_op=True) on RCCL's stream, wait, clip, step.  A one-rank all-reduce is the
+    identity, so the result must equal the plain single-process path up to float-atomic summation order."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _stepper_worker as W
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               KZV_FORCE_DIST="1")
+    env.pop("KZV_DIST_BACKEND", None); env.pop("KZV_CU_RESERVE", None); env.pop("NCCL_MAX_NCHANNELS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_stepper_worker.py"), str(tmp_path)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = torch.load(tmp_path / "rank0.pt")
+    assert got["backend"] == "nccl" and got["dp_path"] is True and got["nchannels"] == "16" and len(got["buckets"]) >= 2
+    cfg = W.run_config()
+    m = _make(cfg, tmp_path, 4, learning_rate=W.LR, beta2=W.BETA2)
+    opt = m.configure_optimizers()
+    from kzv.trainer import Stepper
+    st = Stepper(m, opt, world=1, max_grad_norm=1.0, dp_path=False)
+    m.train()
+    for step in range(W.STEPS):
+        st.step(W.shard_batch(cfg, step, 0, 1, W.PER_RANK), step)
+        assert abs(opt.grad_norm() - got["norms"][step]) < 1e-4 * got["norms"][step] + 1e-9
+    torch.cuda.synchronize()
+    mine, theirs = P.state_dict_from_flat(cfg, m.flat_params.cpu().numpy()), P.state_dict_from_flat(cfg, got["params"].numpy())
+    init = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 4))
+    for k in mine:
+        if k.endswith("key.bias"):
+            continue
+        step_k = float(np.abs(mine[k] - init[k].reshape(mine[k].shape)).max())
+        assert np.abs(mine[k] - theirs[k]).max() < 0.02 * step_k + 1e-7, (k, step_k)
 
 
 # ----------------------------------------------------------------------------------------------- DP kernel selections

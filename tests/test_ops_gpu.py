@@ -2,6 +2,7 @@
 bf16-rounded inputs.  Tolerances are stated per test; bf16 outputs carry 2^-8 relative rounding."""
 import ctypes as C
 
+import numpy as np
 import pytest
 import torch
 
@@ -261,6 +262,64 @@ def test_attention_fwd_bwd(lib, B, heads, Sq, Sk, mode):
     assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("pairs,Sq,Sk,p", [(5, 161, 161, 0.1), (3, 60, 160, 0.1), (2, 7, 5, 0.5), (1, 257, 257, 0.25), (4, 33, 18, 0.0)])
+def test_attention_dropout_mask_entry_equals_the_numpy_statement(lib, pairs, Sq, Sk, p):
+    """kzv_debug_attn_dropout_mask (the device generator, scalar form) bit for bit against oracle/attn_dropout.py."""
+    from oracle import attn_dropout as AD
+    out = torch.empty(pairs * Sq, Sk, device=DEV)
+    for key in (0, 0xdeadbeef, 12345):
+        L.check(lib.kzv_debug_attn_dropout_mask(key, p, pairs, Sq, Sk, out.data_ptr(), _st()), "mask")
+        assert np.array_equal(out.cpu().numpy(), AD.multiplier(key, p, pairs, Sq, Sk)), key
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,mode,drop", [(3, 12, 161, 161, 0, 0.1), (2, 4, 60, 160, 0, 0.1), (2, 4, 127, 160, 0, 0.3),
+                                                     (3, 4, 60, 60, 1, 0.1), (2, 2, 127, 127, 1, 0.1), (2, 3, 100, 100, 0, 0.1),
+                                                     (2, 3, 257, 257, 0, 0.1), (1, 2, 192, 176, 0, 0.1), (2, 2, 16, 16, 0, 0.1)])
+def test_attention_fwd_bwd_with_dropout_against_explicit_masks(lib, B, heads, Sq, Sk, mode, drop):
+    """Dropout ON, every instance of the MFMA kernels (exact 11- and 10-tile, generic <= 192 and <= 288, causal): the PACKED
+    generator inside the kernels (forward: 4 keys of one query per lane; backward: 4 queries of one key) must draw exactly the
+    masks the scalar debug entry reports -- forward output and all three gradients against fp32 torch math on those masks."""
+    torch.manual_seed(Sq * 3 + Sk + mode)
+    H = heads * 64
+    q = torch.randn(B, Sq, H, device=DEV).bfloat16()
+    k = torch.randn(B, Sk, H, device=DEV).bfloat16()
+    v = torch.randn(B, Sk, H, device=DEV).bfloat16()
+    ids, amask = None, None
+    if mode == 1:
+        ids = torch.randint(5, 50, (B, Sk + 1), device=DEV, dtype=torch.int64)
+        for b in range(B):
+            ids[b, Sk - 2 - 5 * b:] = 1
+        amask = torch.ones(Sq, Sk, dtype=torch.bool, device=DEV).tril()[None, None] & (ids[:, :Sk] != 1)[:, None, None, :]
+    key = 77 + Sq
+    dmask = torch.empty(B * heads * Sq, Sk, device=DEV)
+    L.check(lib.kzv_debug_attn_dropout_mask(key, drop, B * heads, Sq, Sk, dmask.data_ptr(), _st()), "mask")
+    dmask = dmask.view(B, heads, Sq, Sk)
+    assert 0.5 * drop < (dmask == 0).float().mean().item() < 1.5 * drop
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, heads, 64).transpose(1, 2) for t in (qf, kf, vf))
+    sc = qh @ kh.transpose(2, 3) * 0.125
+    if amask is not None:
+        sc = sc.masked_fill(~amask, float("-inf"))
+    ref = ((torch.softmax(sc, -1) * dmask) @ vh).transpose(1, 2).reshape(B, Sq, H)
+    do = torch.randn(B, Sq, H, device=DEV).bfloat16()
+    ref.backward(do.float())
+    o = torch.empty(B, Sq, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, Sq, device=DEV)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    a = L.kzv_attn_args(Q=q.data_ptr(), K=k.data_ptr(), V=v.data_ptr(), O=o.data_ptr(), LSE=lse.data_ptr(),
+                        dO=do.data_ptr(), dQ=dq.data_ptr(), dK=dk.data_ptr(), dV=dv.data_ptr(),
+                        ldq=H, ldk=H, ldv=H, ldo=H, ids=L.ptr(ids), ld_ids=Sk + 1, pad_id=1,
+                        B=B, heads=heads, Sq=Sq, Sk=Sk, mode=mode, drop_p=drop, drop_key=key)
+    L.check(lib.kzv_attn_fwd(C.byref(a), _st()), "attn_fwd")
+    L.check(lib.kzv_attn_bwd(C.byref(a), _st()), "attn_bwd")
+    # one wrong mask bit moves an output by ~ |v| / Sk >> the bf16 tolerance below
+    assert (o.float() - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
+    for got, want, name in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+        err = (got.float() - want).abs().max().item()
+        assert err < 0.03 * max(1.0, want.abs().max().item()), (name, err)
+    assert (lse - torch.logsumexp(sc, -1)).abs().max().item() < 2e-3         # the log-sum-exp is of the UN-dropped scores
+
+
 def test_attention_dropout_consistent_between_fwd_and_bwd(lib):
     """With dropout on, backward must regenerate the forward's mask: check dV = P_d^T dO through a
     finite-difference-free identity -- run fwd twice with V=e_j probes is overkill; instead verify
@@ -319,7 +378,7 @@ def test_attention_other_head_dims_fwd_bwd(lib, B, heads, S, D, drop):
     L.check(lib.kzv_attn_bwd(C.byref(a), _st()), "attn_bwd")
     mask = torch.ones(B * heads * S, S, device=DEV)
     if drop:
-        L.check(lib.kzv_debug_dropout_mask(key, drop, B * heads * S, S, (S + 1) & ~1, mask.data_ptr(), _st()), "mask")
+        L.check(lib.kzv_debug_attn_dropout_mask(key, drop, B * heads, S, S, mask.data_ptr(), _st()), "mask")
     x = qkv.float().view(B, S, 3, heads, D).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)      # [3, B, h, S, D]
     sc = (x[0] @ x[1].transpose(-1, -2)) * D ** -0.5
     pm = torch.softmax(sc, -1) * mask.view(B, heads, S, S)

@@ -170,3 +170,33 @@ def test_fp8_quantiser_restatement_matches_an_independent_cast():
     assert s.reshape(-1).tolist() == [1.0, 1.0, 7.0 / 448.0]
     assert q[0].abs().max() == 0 and q[2].abs().max() == 448.0
     assert O.next_act_qscale(0.0, 8.0) == 8.0 and O.next_act_qscale(3.0) == 64.0 and O.next_act_qscale(448.0) == 0.5
+
+
+def test_attention_dropout_generator_is_statistically_bernoulli():
+    """The 4 x 4-block generator the attention kernels draw their probability dropout from (oracle/attn_dropout.py restates
+    csrc/kzv_common.h): marginal rate, joint drop rates of neighbours inside and across blocks, across heads and across site
+    keys, and per-row / per-column rates -- all within sampling error of independent Bernoulli(0.1) draws."""
+    from oracle import attn_dropout as AD
+    p, pairs, S = 0.1, 96, 161
+    keys = [0x1234567, 0x9abcdef1]
+    d = [~AD.keep_mask(k, p, pairs, S, S) for k in keys]
+    t = AD.thr16_of(p)
+    assert t == 6554
+    pd = t / 65536.0
+    n = d[0].size
+    for dm in d:
+        assert abs(dm.mean() - pd) < 4 * np.sqrt(pd * (1 - pd) / n)
+        for dq, dk in [(0, 1), (1, 0), (1, 1), (0, 2), (2, 0), (0, 3), (3, 0), (2, 2), (0, 4), (4, 0), (4, 4), (1, 3), (3, 1), (0, 8), (8, 0)]:
+            a, b = dm[:, :S - dq, :S - dk], dm[:, dq:, dk:]
+            pj = (a & b).mean()
+            assert abs(pj - pd * pd) < 5 * np.sqrt(pd * pd * (1 - pd * pd) / a.size), (dq, dk, pj)
+        pj = (dm[:-1] & dm[1:]).mean()                                       # same (q, k) of the next head
+        assert abs(pj - pd * pd) < 5 * np.sqrt(pd * pd / dm[1:].size)
+        rows, cols = dm.mean(axis=2).ravel(), dm.mean(axis=1).ravel()
+        assert abs(rows.std() / np.sqrt(pd * (1 - pd) / S) - 1) < 0.03 and abs(cols.std() / np.sqrt(pd * (1 - pd) / S) - 1) < 0.03
+    pj = (d[0] & d[1]).mean()                                                # two sites / steps
+    assert abs(pj - pd * pd) < 5 * np.sqrt(pd * pd / n)
+    # the multiplier form the debug entry reports, ragged sizes, and p = 0
+    m = AD.multiplier(7, 0.1, 3, 5, 7)
+    assert m.shape == (15, 7) and set(np.unique(m)).issubset({np.float32(0.0), np.float32(65536.0) / np.float32(65536 - 6554)})
+    assert AD.keep_mask(7, 0.0, 2, 3, 3).all()

@@ -207,8 +207,9 @@ def test_twenty_step_trajectory_matches_oracle(tmp_path):
     print(f"trajectory: relative L2 error of the parameter update {rel:.4f}; min cosine {min(cos.values()):.4f}")
     # Adam divides by sqrt(v): elements whose gradient is below the bf16 noise floor take +-lr steps of arbitrary sign, so
     # the update is compared as a whole (L2) and per tensor by direction
-    assert rel < 0.25
-    assert min(cos.values()) > 0.9, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+    # observed on MI355X: 0.017 / 0.994 -- the bounds are 3x that, not an order of magnitude
+    assert rel < 0.05
+    assert min(cos.values()) > 0.98, sorted(cos.items(), key=lambda kv: kv[1])[:5]
     # second-moment state (no normalisation): tight
     vh = P.state_dict_from_flat(cfg, opt.v.cpu().numpy())
     for k in ("encoder.encoder.layer.0.intermediate.dense.weight", "decoder.roberta.encoder.layer.1.output.dense.weight",

@@ -159,3 +159,23 @@ def test_graph_replayed_decode_step_equals_the_eager_step(trained, monkeypatch):
             outs.setdefault(mode, []).append(m.generate(px, max_length=20, num_beams=beams, early_stopping=False).cpu().numpy())
         assert np.array_equal(outs["1"][0], outs["1"][1])
         assert outs["0"][0].shape == outs["1"][0].shape and np.array_equal(outs["0"][0], outs["1"][0]), beams
+
+
+def test_decode_graph_does_not_outlive_a_rebind(trained, monkeypatch):
+    """A captured decode step bakes in workspace-internal pointers.  generate at (B, L), then a LARGER bind (the host mirror
+    reallocates its workspace on growth), then generate at the first shape again: the replayed step must be re-captured, not
+    replayed against the freed workspace (kzv_model_bind drops the graphs).  Checked against the eager step."""
+    g, cfg, sd, data, m = trained
+    px = torch.from_numpy(data["fit"][0])
+    monkeypatch.setenv("KZV_DECODE_GRAPH", "1")
+    first = m.generate(px, max_length=20, num_beams=1).cpu().numpy()
+    ws_before = m._ws.data_ptr()
+    big = torch.from_numpy(np.concatenate([data["fit"][0]] * 4 + [data["unseen"][0]]))
+    m.generate(big, max_length=24, num_beams=4, early_stopping=False)           # grows the workspace: new allocation
+    junk = torch.full((m._ws.numel() // 4,), float("nan"), device=m.device)      # whatever the allocator recycles is poisoned
+    del junk
+    again = m.generate(px, max_length=20, num_beams=1).cpu().numpy()
+    monkeypatch.setenv("KZV_DECODE_GRAPH", "0")
+    eager = m.generate(px, max_length=20, num_beams=1).cpu().numpy()
+    assert m._ws.data_ptr() != ws_before or m._ws.numel() > 0
+    assert np.array_equal(first, again) and np.array_equal(again, eager)

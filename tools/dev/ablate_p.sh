@@ -5,6 +5,8 @@
 set -e
 SRC=kuzushiji-vision_amd/csrc/gemm_nt256p.hip
 cp $SRC /tmp/p_orig.hip
+# whatever happens below, leave the tree as it was: the pristine source back and libkzv.so rebuilt from it
+trap 'cp /tmp/p_orig.hip $SRC; touch $SRC; make -C kuzushiji-vision_amd/csrc -j8 > /dev/null 2>&1' EXIT
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -ffp-contract=fast -DKZV_STAMPS"
 run() {
   make -C kuzushiji-vision_amd/csrc -j8 FLAGS="$FL" > /dev/null 2>&1

@@ -21,12 +21,13 @@ for i in range(12):
     r = [x for x in t[i].tolist() if x]
     print(f"block {i * 257:5d}: " + " ".join(f"{(x - t0) / 100:7.2f}" for x in r))
 
-# ---- backward timeline of one workgroup (block 771, thread 0): staged | per q-block: phase A end, barrier, phase B end, barrier
+# ---- backward timeline of one workgroup (block 771, thread 0): start, DMA issued, delta done, staged | per q-block: after each
+# owned key tile, phase A end, barrier, dQ MFMAs done, phase B end, barrier
 do = torch.randn(B * Sq, H, device=dev).bfloat16(); dqkv = torch.zeros_like(qkv)
 a.dO = do.data_ptr(); a.dQ = dqkv.data_ptr(); a.dK = dqkv[:, H:].data_ptr(); a.dV = dqkv[:, 2 * H:].data_ptr()
 for _ in range(3): L.check(lib.kzv_attn_bwd(C.byref(a), torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 raw = C.CDLL(L.__dict__.get("_path", None) or os.path.join(ROOT, "kuzushiji-vision_amd", "kzv", "libkzv.so"))
 assert raw.kzv_debug_bwd_stamps(buf) == 0
 r = [x for x in buf if x]

@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def source_sha16():      # same recipe as bench.py::source_sha16
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "kuzushiji-vision_amd", "csrc", "*.[hc]*"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "kuzushiji-vision_amd", "csrc", "*.[hc]*"))) + [os.path.join(ROOT, "include", "kzv.h"),
+                                                                                                  os.path.join(ROOT, "kuzushiji-vision_amd", "csrc", "Makefile")]:
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
