@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--dec-layers", type=int, default=6, help="6 = BASELINE.json configs[1]; 12 = reference decoder")
     ap.add_argument("--encoder", choices=["vit_b", "vit_l"], default="vit_b",
                     help="vit_b = the benchmark (configs[1]/[2]); vit_l = configs[3]'s ViT-L/16 encoder (a side measurement)")
+    ap.add_argument("--wide-decoder", action="store_true",
+                    help="with --encoder vit_l: the 1024 / 16-head / FFN-4096 decoder SURVEY.md section 8(d) prices configs[3] with "
+                         "(468 GFLOP per image at 12 layers) instead of the reference decoder's 256 / 4 / 768 widths")
     ap.add_argument("--fp8-mode", type=int, default=2, choices=[1, 2], help="with --fp8: 1 = forward GEMMs only, 2 = + the MLP's input-gradient GEMMs")
     ap.add_argument("--fp8", action="store_true",
                     help="side measurement (configs[4], second half): the encoder's QKV / fc1 / fc2 forward GEMMs on e4m3 operands; "
@@ -173,7 +176,7 @@ def main():
 
     import torch
     from kzv import _lib as L
-    from kzv.config import vit_b_config, vit_l_config
+    from kzv.config import vit_b_config, vit_l_config, vit_l_wide_config
     from kzv.data import build_decoder_dir, synthetic_batch
     from kzv.model import TrOCRModel
     from kzv.trainer import Stepper, init_distributed
@@ -183,7 +186,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    cfg = vit_b_config(dec_layers=args.dec_layers) if args.encoder == "vit_b" else vit_l_config(dec_layers=args.dec_layers)
+    if args.wide_decoder and args.encoder != "vit_l":
+        raise SystemExit("--wide-decoder goes with --encoder vit_l")
+    cfg = (vit_b_config(dec_layers=args.dec_layers) if args.encoder == "vit_b" else
+           vit_l_wide_config(dec_layers=args.dec_layers) if args.wide_decoder else vit_l_config(dec_layers=args.dec_layers))
     lib = L.load()
 
     with tempfile.TemporaryDirectory() as tmp:
@@ -286,7 +292,7 @@ def main():
         import glob
         for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
             j = json.load(open(tj))
-            if j.get("source_sha16") == source_sha16() and args.batch == 256 and args.dec_layers == 6 and args.encoder == "vit_b" and not args.fp8:
+            if j.get("source_sha16") == source_sha16() and args.batch == 256 and args.dec_layers == 6 and args.encoder == "vit_b" and not args.fp8 and not args.wide_decoder:
                 k = j["kernels"].get("gemm_nt_kernel<*>")
                 if k:
                     traffic, traffic_src = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], os.path.relpath(tj, ROOT)
@@ -298,7 +304,7 @@ def main():
             "dtype": "bf16" if not args.fp8 else "bf16 + e4m3 (encoder QKV/fc1/fc2 forward GEMMs): side measurement, not the benchmark line",
             "data": "synthetic",
             "config": {"workload": f"TrOCR train step: {'ViT-B/16 (12L/768/12h/3072)' if args.encoder == 'vit_b' else 'ViT-L/16 (24L/1024/16h/4096)'} on 64x640 crops (S_e=161) + RoBERTa "
-                                   f"decoder {args.dec_layers}L/256/4h/768, V=4300 one-char vocab, labels [B,{args.label_len}], "
+                                   f"decoder {args.dec_layers}L/{cfg.dec_hidden}/{cfg.dec_heads}h/{cfg.dec_ffn}, V=4300 one-char vocab, labels [B,{args.label_len}], "
                                    f"dropout 0.1, clip 1.0, RAdamScheduleFree; BASELINE.json configs[{(1 if world == 1 else 2) if args.encoder == 'vit_b' else 3}]",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "decoder_positions": DECPOS,

@@ -211,17 +211,19 @@ constexpr int bwd_lds_bytes(int NKT) {
 }
 static_assert(bwd_lds_bytes(12) <= 80 * 1024, "attention backward (<= 192 tokens) must fit two workgroups per CU");
 
-// stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces spread over the NW waves
+// stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces spread over the NW waves.  Rows past the last query are CLAMPED to
+// it, not zero-filled: their log-sum-exp is +inf, so P = dS = 0 there and the (finite) operand rows never reach a result; that
+// keeps the address a wave-uniform base + a 32-bit lane offset.
 template <int NW>
-__device__ __forceinline__ void stage_slabs(char* qs, char* os, const bf16_t* Qb, const bf16_t* dOb, int64_t ldq, int64_t ldo,
-                                            int row0, int nvalid, const void* zero16, int w, int lane) {
+__device__ __forceinline__ void stage_slabs(char* qs, char* os, const bf16_t* Qb, const bf16_t* dOb, unsigned ldq, unsigned ldo,
+                                            int row0, int nvalid, int w, int lane) {
     for (int pc = w; pc < 8; pc += NW) {
         const int pq = pc & 3;
         const int row = pq * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ (row & 7);
-        const bool ok = row0 + row < nvalid;
-        if (pc < 4) glds16_asm(ok ? (const void*)(Qb + (int64_t)(row0 + row) * ldq + chunk * 8) : zero16, qs + pq * 1024);
-        else glds16_asm(ok ? (const void*)(dOb + (int64_t)(row0 + row) * ldo + chunk * 8) : zero16, os + pq * 1024);
+        const unsigned chunk = (lane & 7) ^ (row & 7);
+        const unsigned r = (unsigned)min(row0 + row, nvalid - 1);
+        if (pc < 4) glds16_asm_soff(Qb, (r * ldq + chunk * 8) * 2, qs + pq * 1024);
+        else glds16_asm_soff(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
     }
 }
 template <int SP, int NW>
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
     }
     stage_image_asm<SP, NW>(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
     stage_image_asm<NKT * 16, NW>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
-    stage_slabs<NW>(Qring, Oring, Qb, dOb, p.ldq, p.ldo, 0, p.Sq, p.zero16, w, lane);
+    stage_slabs<NW>(Qring, Oring, Qb, dOb, (unsigned)p.ldq, (unsigned)p.ldo, 0, p.Sq, w, lane);
     KZV_BSTAMP();
     const float keep_p = 1.f / p.inv_keep;
 #pragma unroll
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         for (int dt = 0; dt < 4; ++dt) tT[dt] = row * 128 + ((((dt * 2 + hb) ^ (row & 7))) << 4) + (l15 & 1) * 8;
     }
     const AttDropLane dl = att_drop_lane(l15 & 3, false);
-    const int thr_s = (int)p.thr16 - 32768;
+    const int thr_s = p.thr16 ? (int)p.thr16 - 32768 : -40000;          // no dropout: below every int16, everything is kept
     const unsigned nQ4 = (unsigned)(p.Sq + 3) >> 2, nK4 = (unsigned)(p.Sk + 3) >> 2;
     // pre-mix word of block (q >> 2 = g, k >> 2 = l15 >> 2) of slab 0; + per slab / 16-query half / key tile multiples of GOLD
     unsigned xslab = (((unsigned)(b * p.heads + h) * nQ4 + g) * nK4 + (l15 >> 2)) * KZV_ATT_GOLD + p.key;
@@ -328,22 +330,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
     for (int qb = 0; qb < nqb; ++qb) {
         const char* Qs = Qring + (qb & 1) * SLAB;
         const char* Os = Oring + (qb & 1) * SLAB;
-        if (qb + 1 < nqb)      // next slab flies during this block's two phases
-            stage_slabs<NW>(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, p.ldq, p.ldo, (qb + 1) * 32, p.Sq, p.zero16, w, lane);
         // ---------------- phase A: per owned key tile, S / dP / P / dS for 32 queries; dV^T, dK^T ----------
-        bf16x8 dOt[4], Qt[4];     // A operands shared by all key tiles of this wave: dO^T and Q^T over the slab
+        // The row fragments of Q and dO (A operands of S and dP) are shared by every key tile of this wave: read ONCE per slab.
+        // dO^T and Q^T over the slab (A operands of the dV / dK products) are re-read per tile, late, when the S / dP registers
+        // are free again: kept across the tiles too, they make the kernel spill.  (log-sum-exp and delta' of the lane's rows are
+        // re-read per tile as two 16-byte pieces: kept across the tiles they cost the 16 registers that make the kernel spill.)
+        bf16x8 Qr[2][2], Or[2][2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dOt[dt] = cat8(lds_tr16(Os + tT[dt]), lds_tr16(Os + tT[dt] + 2048));
-            Qt[dt] = cat8(lds_tr16(Qs + tT[dt]), lds_tr16(Qs + tT[dt] + 2048));
+        for (int t2 = 0; t2 < 2; ++t2) {
+            Qr[t2][0] = *(const bf16x8*)(Qs + rA + t2 * 2048); Qr[t2][1] = *(const bf16x8*)(Qs + rB + t2 * 2048);
+            Or[t2][0] = *(const bf16x8*)(Os + rA + t2 * 2048); Or[t2][1] = *(const bf16x8*)(Os + rB + t2 * 2048);
         }
+        // the next slab flies during this block's two phases; its (slow to issue) DMAs go out behind the LDS reads above
+        if (qb + 1 < nqb)
+            stage_slabs<NW>(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, (unsigned)p.ldq, (unsigned)p.ldo, (qb + 1) * 32, p.Sq, w, lane);
         KZV_BSTAMP();
-        float lq[8], dq8[8];      // log-sum-exp and delta' of this lane's 8 query rows: read once per slab, not per key tile
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int q = qb * 32 + (r >> 2) * 16 + 4 * g + (r & 3);
-            lq[r] = lse[q]; dq8[r] = dlt[q];
-        }
 #pragma unroll
         for (int a = 0; a < TPW; ++a) {
             const int kt = w + NW * a;
@@ -365,23 +366,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
             unsigned pdw[4], dsw[4];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
+                const f32x4 lq4 = *(const f32x4*)(lse + qb * 32 + t2 * 16 + 4 * g), dq4 = *(const f32x4*)(dlt + qb * 32 + t2 * 16 + 4 * g);
                 f32x4 S = (f32x4){sinit, sinit, sinit, sinit}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
-                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + rA + t2 * 2048), k0, S, 0, 0, 0);
-                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + rB + t2 * 2048), k1, S, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Os + rA + t2 * 2048), v0, dP, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Os + rB + t2 * 2048), v1, dP, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qr[t2][0], k0, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qr[t2][1], k1, S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Or[t2][0], v0, dP, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Or[t2][1], v1, dP, 0, 0, 0);
                 unsigned u01 = 0, u23 = 0;
                 if (p.thr16)      // block (q >> 2 = qb * 8 + t2 * 4 + g, key >> 2 = kt * 4 + (l15 >> 2)); this lane's column is key & 3
                     att_drop_u(dl, att_mix(xslab + (unsigned)t2 * xstep_t2 + (unsigned)kt * (4u * KZV_ATT_GOLD)), &u01, &u23);
                 float pm[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(fmaf(S[r], sc, -lq[t2 * 4 + r]));      // lse = +inf for q >= Sq / dead rows
+                    float pr = __builtin_amdgcn_exp2f(fmaf(S[r], sc, -lq4[r]));      // lse = +inf for q >= Sq / dead rows
                     if (MODE == 1) pr = key <= qb * 32 + t2 * 16 + 4 * g + r ? pr : 0.f;     // causal
                     const unsigned ur = (r & 2) ? u23 : u01;
                     const int us = (r & 1) ? (int)ur >> 16 : (int)(short)(ur & 0xffffu);
-                    pm[r] = (!p.thr16 || us >= thr_s) ? pr : 0.f;
-                    ds[r] = fmaf(pm[r], dP[r], -pr * dq8[t2 * 4 + r]);
+                    pm[r] = us >= thr_s ? pr : 0.f;
+                    ds[r] = fmaf(pm[r], dP[r], -pr * dq4[r]);
                 }
                 pdw[t2 * 2] = pack_bf2(pm[0], pm[1]); pdw[t2 * 2 + 1] = pack_bf2(pm[2], pm[3]);
                 dsw[t2 * 2] = pack_bf2(ds[0], ds[1]); dsw[t2 * 2 + 1] = pack_bf2(ds[2], ds[3]);
@@ -390,8 +392,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
             const bf16x8 pf = words8(pdw[0], pdw[1], pdw[2], pdw[3]), df = words8(dsw[0], dsw[1], dsw[2], dsw[3]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOt[dt], pf, dv[a][dt], 0, 0, 0);
-                dk[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt[dt], df, dk[a][dt], 0, 0, 0);
+                const bf16x8 dOt = cat8(lds_tr16(Os + tT[dt]), lds_tr16(Os + tT[dt] + 2048));
+                const bf16x8 Qt = cat8(lds_tr16(Qs + tT[dt]), lds_tr16(Qs + tT[dt] + 2048));
+                dv[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOt, pf, dv[a][dt], 0, 0, 0);
+                dk[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qt, df, dk[a][dt], 0, 0, 0);
             }
             KZV_BSTAMP();
         }

@@ -166,11 +166,19 @@ def vit_b_config(dec_layers: int = 12) -> ModelConfig:
                        dec_hidden=256, dec_layers=dec_layers, dec_heads=4, dec_ffn=768, vocab=4300, max_pos=128)
 
 
-def vit_l_config(enc_layers: int = 24, dec_layers: int = 12) -> ModelConfig:
-    """configs[3]: TrOCR-large geometry -- ViT-L/16 encoder (1024 / 16 heads / FFN 4096) on 64x640 crops + the 12-layer
-    reference decoder; `enc_layers` lets tests keep the oracle fast."""
+def vit_l_config(enc_layers: int = 24, dec_layers: int = 12, dec_hidden: int = 256, dec_heads: int = 4, dec_ffn: int = 768) -> ModelConfig:
+    """configs[3]: TrOCR-large geometry -- ViT-L/16 encoder (1024 / 16 heads / FFN 4096) on 64x640 crops.  Two decoder variants:
+    the reference decoder's widths (256 / 4 heads / FFN 768, the default) and, with ``dec_hidden=1024, dec_heads=16,
+    dec_ffn=4096``, the TrOCR-large decoder SURVEY.md section 8(d) prices the config with (468 GFLOP per image; encoder and
+    decoder widths are then equal, so ``encoder_decoder_proj`` is nn.Identity: src/models/trocr_model.py:250-253).
+    `enc_layers` / `dec_layers` let tests keep the oracle fast."""
     return ModelConfig(image_h=64, image_w=640, enc_hidden=1024, enc_layers=enc_layers, enc_heads=16, enc_ffn=4096,
-                       dec_hidden=256, dec_layers=dec_layers, dec_heads=4, dec_ffn=768, vocab=4300, max_pos=128)
+                       dec_hidden=dec_hidden, dec_layers=dec_layers, dec_heads=dec_heads, dec_ffn=dec_ffn, vocab=4300, max_pos=128)
+
+
+def vit_l_wide_config(enc_layers: int = 24, dec_layers: int = 12) -> ModelConfig:
+    """configs[3] as SURVEY.md section 8(d) prices it: ViT-L/16 + a 12-layer decoder at 1024 hidden / 16 heads / FFN 4096."""
+    return vit_l_config(enc_layers, dec_layers, dec_hidden=1024, dec_heads=16, dec_ffn=4096)
 
 
 def small_config() -> ModelConfig:

@@ -116,6 +116,33 @@ def test_config1_full_batch_256_properties(tmp_path):
             assert v.abs().max().item() > 0, k
 
 
+def test_config3_full_size_wide_decoder_properties(tmp_path):
+    """configs[3] at its full size -- ViT-L/16 24L + the 12-layer 1024 / 16-head / FFN-4096 decoder, batch 256 (the size
+    bench.py --encoder vit_l --wide-decoder runs): finite loss near ln(V), every tensor receives a gradient, two same-seed
+    dropout-ON steps agree to float-atomic order and another seed does not.  Element-wise parity of these widths against the
+    oracle is tests/test_model_gpu.py::test_vit_large_with_the_1024_wide_decoder_matches_oracle (reduced depth)."""
+    from kzv.config import vit_l_wide_config
+    cfg = vit_l_wide_config()
+    m = _make(cfg, tmp_path, 42)
+    px, lab = synthetic_batch(cfg, 256, 128, seed=1)
+    pxt, labt = torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()
+    m.train()
+    res = []
+    for seed in (11, 11, 12):
+        loss, _ = m.forward_loss(pxt, labt, seed=seed)
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.item()), m.flat_grads.clone()))
+    assert all(np.isfinite(r[0]) for r in res) and abs(res[0][0] - np.log(cfg.vocab)) < 0.6
+    gmax = res[0][1].abs().max().item()
+    assert torch.isfinite(res[0][1]).all() and gmax > 0
+    assert abs(res[0][0] - res[1][0]) < 1e-4 and (res[0][1] - res[1][1]).abs().max().item() < 1e-3 * gmax
+    assert (res[0][1] - res[2][1]).abs().max().item() > 1e-2 * gmax
+    for k, v in m.grad_dict().items():
+        if not k.endswith("key.bias") and "token_type" not in k:
+            assert v.abs().max().item() > 0, k
+
+
 # ----------------------------------------------------------------------------------------------- DP on one GPU
 def _free_port():
     with socket.socket() as s:

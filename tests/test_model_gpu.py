@@ -342,6 +342,44 @@ def test_vit_large_geometry_matches_oracle(tmp_path):
         assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, k
 
 
+def test_vit_large_with_the_1024_wide_decoder_matches_oracle(tmp_path):
+    """configs[3] as SURVEY.md section 8(d) prices it: ViT-L/16 widths + a decoder at 1024 hidden / 16 heads / FFN 4096, so
+    encoder_decoder_proj is nn.Identity (trocr_model.py:250-253) -- 2 + 2 layers for the CPU oracle.  Train step (logits,
+    loss, every gradient) and the greedy decode, KV-cached (the few-rows GEMMs without the 256-wide LayerNorm folding)
+    against the prefix-recompute form and against the oracle's step-wise forward."""
+    from kzv.config import vit_l_wide_config
+    cfg = _no_dropout(vit_l_wide_config(enc_layers=2, dec_layers=2))
+    assert not cfg.has_proj and cfg.dec_hidden // cfg.dec_heads == 64
+    m = _make(cfg, tmp_path, 6)
+    px, lab = synthetic_batch(cfg, 3, 24, seed=12, min_chars=3, max_chars=20)
+    m.train()
+    out = m(torch.from_numpy(px), torch.from_numpy(lab))
+    m.backward()
+    torch.cuda.synchronize()
+    sd = P.state_dict_from_flat(cfg, P.recipe_flat(cfg, 6))
+    r = O.forward_backward(cfg, sd, px, lab)
+    assert np.abs(out["logits"].cpu().numpy() - r["logits"]).max() < LOGIT_TOL
+    assert abs(float(out["loss"]) - r["loss"]) < 5e-3
+    g = m.grad_dict()
+    assert not any(k.startswith("encoder_decoder_proj") for k in g)
+    for k, v in r["grads"].items():
+        if v is None or k.endswith("key.bias"):
+            continue
+        got = g[k].cpu().numpy().reshape(v.shape)
+        assert np.abs(got - v).max() < 0.05 * np.abs(v).max() + 1e-7, k
+    # generation: KV-cached and prefix-recompute against the oracle's step-wise forward, up to the first undecided step
+    m.eval()
+    want, gaps = O.greedy_stepwise(cfg, O.leaf_state_dict(sd, requires_grad=False), px, 12)
+    for uc in (True, False):
+        gen = m.generate(torch.from_numpy(px), max_length=12, num_beams=1, use_cache=uc).cpu().numpy()
+        full = np.full((px.shape[0], 12), cfg.pad_id, dtype=np.int64)
+        full[:, :gen.shape[1]] = gen
+        for row in range(px.shape[0]):
+            und = gaps[row] <= 2 * LOGIT_TOL
+            first = int(np.argmax(und)) if und.any() else 11
+            assert np.array_equal(full[row, :first + 1], want[row, :first + 1]), (uc, row)
+
+
 def test_zero_layer_models_are_rejected(tmp_path):
     import dataclasses
     from kzv._lib import KzvError
