@@ -318,6 +318,60 @@ typedef struct kzv_attn_args {
 int kzv_attn_fwd(const kzv_attn_args* a, void* stream);
 int kzv_attn_bwd(const kzv_attn_args* a, void* stream);
 
+/* ------------------------------------------------------------- the ResNet / BiLSTM / CTC model of ocr_lightning/model.py
+ * (SURVEY.md section 8(f), row N3).  Per-op entry points; the host mirror kzv/ocr_model.py strings them together the way
+ * OCRModel.forward / _shared_step do (ocr_lightning/model.py:61-88, 90-195).  Activations are NHWC (rows = pixels, columns =
+ * channels) so that a convolution is kzv_ocr_im2col + kzv_gemm_nt, its weight gradient kzv_gemm_tn on the same column matrix and
+ * its input gradient kzv_gemm_nt against the transposed packed weight + kzv_ocr_col2im.  bf16 GEMM operands, fp32 everything else. */
+/* images fp32 [N, C, H, W] (ocr_collate_fn's stack, dataset.py:100) -> NHWC bf16 */
+int kzv_ocr_nchw_to_nhwc(const float* x, void* out_bf16, int N, int C, int H, int W, void* stream);
+/* nn.Conv2d forward operand (resnet34's 7x7/2, 3x3/1, 3x3/2 and 1x1/2 convolutions, model.py:31-32): cols bf16 [N*Ho*Wo, Kp],
+ * column (kh * KW + kw) * C + c, Kp >= KH*KW*C a multiple of 8 (the GEMM wants a multiple of 64), zero-filled padding. */
+int kzv_ocr_im2col(const void* x_bf16, void* cols_bf16, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kp, void* stream);
+/* nn.Conv2d input gradient from the gradient of the column matrix (fp32 [N*Ho*Wo, Kp]): dx fp32 [N, H, W, C] (+= if accumulate) */
+int kzv_ocr_col2im(const float* dcols, float* dx, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kp, int accumulate, void* stream);
+/* conv weight fp32 [Cout, Cin, KH, KW] (the state_dict layout) -> packed bf16 [Cout, Kp] (+ its transpose [Kp, Cout] if wpT) */
+int kzv_ocr_conv_weight(const float* w, void* wp_bf16, void* wpT_bf16, int Cout, int Cin, int KH, int KW, int Kp, void* stream);
+/* gradient of the packed weight fp32 [Cout, Kp] accumulated into the state_dict layout [Cout, Cin, KH, KW] */
+int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, int Cin, int KH, int KW, int Kp, void* stream);
+/* nn.BatchNorm2d (+ the BasicBlock's residual add and ReLU): out bf16 = [relu](gamma * (y - mean) * rstd + beta [+ resid]); y fp32
+ * [M, C].  train: batch statistics (biased variance), running statistics updated with `momentum` and the unbiased variance;
+ * eval: the running statistics.  mean / rstd [C] are kept for the backward.  d_scratch: 2 * C floats. */
+int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
+                   float* rstd, const void* resid_bf16, void* out_bf16, int relu, int train, float eps, float momentum, float* d_scratch, void* stream);
+/* its backward: da fp32 [M, C] = gradient of the (post-ReLU) output; dz fp32 = da masked by the ReLU (also the gradient of the
+ * residual input); dgamma / dbeta must arrive ZEROED (they are needed complete by the second pass); dy bf16 = gradient of y. */
+int kzv_ocr_bn_bwd(const float* da, const void* a_bf16, const float* y, int64_t M, int C, const float* mean, const float* rstd, const float* gamma,
+                   float* dz, float* dgamma, float* dbeta, void* dy_bf16, int relu, int train, void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem, NHWC bf16; idx = winning tap per output (first maximum, like torch) */
+int kzv_ocr_maxpool_fwd(const void* x_bf16, void* out_bf16, unsigned char* idx, int N, int H, int W, int C, void* stream);
+int kzv_ocr_maxpool_bwd(const float* dout, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* nn.AdaptiveAvgPool2d((1, 1)) + flatten (model.py:34, 66-67): feat fp32 and bf16 [N, C] */
+int kzv_ocr_avgpool_fwd(const void* x_bf16, float* feat_f32, void* feat_bf16, int N, int HW, int C, void* stream);
+int kzv_ocr_avgpool_bwd(const float* dfeat, float* dx, int N, int HW, int C, void* stream);
+/* One nn.LSTM direction on a length-1 sequence with zero initial state (model.py:40-47, 73-75): gates fp32 [B, 4H] = x W_ih^T + b_ih
+ * (a kzv_gemm_nt; torch order i, f, g, o), b_hh [4H] added here; h written into columns of the [B, ldh] output (forward | reverse
+ * halves).  With h0 = c0 = 0 the recurrent weight W_hh multiplies zeros and the forget gate receives no gradient. */
+int kzv_ocr_lstm_cell_fwd(const float* gates, const float* b_hh, float* h_f32, void* h_bf16, int64_t ldh, int B, int H, void* stream);
+int kzv_ocr_lstm_cell_bwd(const float* gates, const float* b_hh, const float* dh, int64_t lddh, void* dgates_bf16, int B, int H, void* stream);
+/* F.log_softmax(dim = -1) on fp32 rows (model.py:125) */
+int kzv_ocr_log_softmax(const float* x, float* lp, int rows, int C, void* stream);
+/* nn.CTCLoss(blank, zero_infinity) on lp fp32 [T, B, C] (model.py:51-55, 171-176): d_nll[b] = -log p(target_b) (0 where infinite and
+ * zero_infinity); if d_dlogits: the gradient with respect to the logits behind lp, times d_gscale[b] (the caller folds the
+ * reduction -- 'mean' = 1 / (max(target_len, 1) * B) -- and the loss weight into it).  d_scratch: 2 * B * T * (2 * max_target_len + 1)
+ * floats.  targets int64 [B, ld_targets]; lengths int64 [B]. */
+int kzv_ocr_ctc(const float* lp, const int64_t* targets, int64_t ld_targets, const int64_t* input_lengths, const int64_t* target_lengths, int T,
+                int B, int C, int blank, int zero_infinity, int max_target_len, float* d_scratch, float* d_nll, const float* d_gscale,
+                float* d_dlogits, void* stream);
+/* The localisation loss of _shared_step (model.py:100-122): mean over the samples with n_i = min(count_i, max_boxes) > 0 of the mean
+ * SmoothL1 (beta 1) between pred[i, :n_i] and gt[i, :n_i].  *d_loss += loss (zero it first); d_dpred fp32 [B, max_boxes, 4]. */
+int kzv_ocr_smooth_l1_boxes(const float* pred, int max_boxes, const float* gt, int gt_boxes, const int32_t* counts, int B, float* d_loss,
+                            float* d_dpred, void* stream);
+/* torch.optim.Adam (model.py:197; no weight decay, no amsgrad), `step` = 1-based step count */
+int kzv_ocr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, void* stream);
+int kzv_ocr_cast_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
+int kzv_ocr_cast_transpose(const float* x, void* out_bf16, int rows, int cols, void* stream);   /* [rows, cols] fp32 -> bf16 [cols, rows] */
+
 /* ------------------------------------------------------------- measurement hooks (bench.py roofline leg)
  * When enabled, every launch of the hot kernels is bracketed by HIP events on its own stream.
  * kind: 0 gemm_nt, 1 gemm_tn, 2 attn_fwd, 3 attn_bwd, 4 gemm_nt_fp8.  work = algorithmic FLOPs (2*M*N*K; 4*B*h*Sq*Sk*64 /

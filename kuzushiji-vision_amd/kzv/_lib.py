@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkzv.so")
+LIB_PATH = os.environ.get("KZV_LIB") or os.path.join(_HERE, "libkzv.so")      # KZV_LIB: dev knob (A/B of two builds on one box)
 
 
 class KzvError(RuntimeError):
@@ -131,6 +131,26 @@ SYMBOLS = {
     "kzv_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "kzv_debug_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "kzv_debug_attn_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    # ---- ocr_lightning/model.py path (csrc/ocr.hip)
+    "kzv_ocr_nchw_to_nhwc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "kzv_ocr_im2col": (C.c_int, [_P, _P] + [C.c_int] * 9 + [_P]),
+    "kzv_ocr_col2im": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
+    "kzv_ocr_conv_weight": (C.c_int, [_P, _P, _P] + [C.c_int] * 5 + [_P]),
+    "kzv_ocr_conv_wgrad_unpack": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
+    "kzv_ocr_bn_fwd": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
+    "kzv_ocr_bn_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "kzv_ocr_maxpool_fwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "kzv_ocr_maxpool_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "kzv_ocr_avgpool_fwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "kzv_ocr_avgpool_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "kzv_ocr_lstm_cell_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "kzv_ocr_lstm_cell_bwd": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_int, C.c_int, _P]),
+    "kzv_ocr_log_softmax": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "kzv_ocr_ctc": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "kzv_ocr_smooth_l1_boxes": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "kzv_ocr_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+    "kzv_ocr_cast_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "kzv_ocr_cast_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),
     "kzv_prof_select": (C.c_int, [C.c_uint]),
     "kzv_prof_sample": (C.c_int, [C.c_int]),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """CLI entrypoint of the MI355X engine: the flag surface of scripts/train_trocr.py:23-71 (TrOCR) plus the
-ocr_lightning/train.py:161-189 spellings, wired to kzv.TrOCRModel + kzv.trainer.fit.
+ocr_lightning/train.py:161-189 spellings, wired to kzv.TrOCRModel + kzv.trainer.fit; `--model ocr` trains ocr_lightning/model.py's
+ResNet34 / BiLSTM / CTC OCRModel (kzv.ocr_model) on ocr_lightning/train.py's folder datasets.
 
   python -m kzv.train --synthetic 64 --batch_size 32 --encoder_hidden_size 384 --encoder_num_layers 6 \
          --encoder_num_heads 6 --image_size 64 640 --max_epochs 1            # BASELINE.json configs[0] plumbing
@@ -61,11 +62,82 @@ def parse_args(argv=None):
                    help="resize / pad / normalise the decoded crops on the GPU (kzv.preprocess; byte-exact with the PIL transform)")
     p.add_argument("--skip_test", action="store_true", help="do not run the reference's post-fit test phase (scripts/train_trocr.py:193-195)")
     p.add_argument("--ema_decay", type=float, default=0.0, help="> 0 attaches kzv.ema.EMACallback (reference: decay 0.9999)")
+    # the ResNet34 / BiLSTM / CTC model of ocr_lightning/model.py behind ocr_lightning/train.py's own flags (:161-189)
+    p.add_argument("--model", type=str, default="trocr", choices=["trocr", "ocr"],
+                   help="trocr = scripts/train_trocr.py's model (the benchmark path); ocr = ocr_lightning/train.py's OCRModel "
+                        "(--train_data_dir / --val_data_dir folder datasets, Adam, early stopping on val/total_loss)")
+    p.add_argument("--checkpoint_dir", type=str, default="./ocr_checkpoints")
+    p.add_argument("--log_dir", type=str, default="./ocr_logs")
+    p.add_argument("--max_boxes", type=int, default=50)
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--patience", type=int, default=3)
     return p.parse_args(argv)
+
+
+def main_ocr(args):
+    """ocr_lightning/train.py:35-158: seed, folder datasets + pad-collate loaders, OCRModel, ModelCheckpoint(monitor val/total_loss,
+    save_top_k=1, save_last) + EarlyStopping(patience) over `--epochs` epochs of Adam steps; per-epoch metrics as JSON lines in --log_dir
+    (the reference writes TensorBoard events; there is no tensorboard in this image)."""
+    import json
+    import torch
+    from .ocr_data import CHAR_TO_IDX, IDX_TO_CHAR, OcrDataset, OcrLoader
+    from .ocr_model import OCRModel
+    if not args.train_data_dir or not args.val_data_dir:
+        raise SystemExit("--model ocr needs --train_data_dir and --val_data_dir (ocr_lightning/train.py:163-164)")
+    if args.accelerator not in ("gpu", "auto"):
+        raise SystemExit("this engine runs on MI355X GPUs only")
+    torch.manual_seed(args.seed)
+    os.makedirs(args.checkpoint_dir, exist_ok=True); os.makedirs(args.log_dir, exist_ok=True)
+    train_ds = OcrDataset(args.train_data_dir, char_to_idx=CHAR_TO_IDX)
+    val_ds = OcrDataset(args.val_data_dir, char_to_idx=CHAR_TO_IDX)
+    if len(train_ds) == 0:
+        print(f"Error: Training dataset at {args.train_data_dir} is empty. Please check the path and data structure.")
+        return None
+    train_loader = OcrLoader(train_ds, args.batch_size, shuffle=True, seed=args.seed)
+    val_loader = OcrLoader(val_ds, args.batch_size) if len(val_ds) else None
+    model = OCRModel(CHAR_TO_IDX, IDX_TO_CHAR, learning_rate=args.learning_rate, max_boxes=args.max_boxes, init_seed=args.seed)
+    model.configure_optimizers()
+    best, best_path, bad, hist = float("inf"), None, 0, []
+    log = open(os.path.join(args.log_dir, "metrics.jsonl"), "a", encoding="utf-8")
+    for epoch in range(args.epochs):
+        train_loader.set_epoch(epoch)
+        model.logged.clear()
+        for i, batch in enumerate(train_loader):
+            model.fit_step(batch, i)
+        rec = {"epoch": epoch, **{k: sum(v) / len(v) for k, v in model.logged.items() if k.startswith("train/")}}
+        if val_loader is not None:
+            model.eval(); model.logged.clear()
+            for i, batch in enumerate(val_loader):
+                model.validation_step(batch, i)
+            rec.update({k: sum(v) / len(v) for k, v in model.logged.items() if k.startswith("val/")})
+            model.train()
+        hist.append(rec); log.write(json.dumps(rec) + "\n"); log.flush()
+        print(" ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()))
+        torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch},
+                   os.path.join(args.checkpoint_dir, "last.ckpt"))
+        vl = rec.get("val/total_loss")
+        if vl is not None:
+            if vl < best:
+                best, bad = vl, 0
+                if best_path and os.path.exists(best_path):
+                    os.remove(best_path)
+                best_path = os.path.join(args.checkpoint_dir, f"ocr-epoch={epoch:02d}-val_total_loss={vl:.2f}.ckpt")
+                torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch}, best_path)
+            else:
+                bad += 1
+                if bad >= args.patience:
+                    print(f"Early stopping: val/total_loss has not improved for {bad} epochs")
+                    break
+    log.close()
+    print(f"Training finished.\nBest model checkpoint saved at: {best_path}" if best_path else "No best model checkpoint was saved.")
+    main_ocr.best_model_path = best_path
+    return hist
 
 
 def main(argv=None):
     args = parse_args(argv)
+    if args.model == "ocr":
+        return main_ocr(args)
     import torch
     from .config import ModelConfig
     from .data import LineCsvDataset, SyntheticLineDataset, build_decoder_dir, make_loader
