@@ -222,8 +222,13 @@ __device__ __forceinline__ void stage_slabs(char* qs, char* os, const bf16_t* Qb
         const int row = pq * 8 + (lane >> 3);
         const unsigned chunk = (lane & 7) ^ (row & 7);
         const unsigned r = (unsigned)min(row0 + row, nvalid - 1);
+#ifdef KZV_ATT_M0_RESTORE
         if (pc < 4) glds16_asm_soff(Qb, (r * ldq + chunk * 8) * 2, qs + pq * 1024);
         else glds16_asm_soff(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
+#else       // every LDS-DMA of the backward kernel is issued from asm: M0 need not be handed back to the compiler
+        if (pc < 4) glds16_asm_soff_m0(Qb, (r * ldq + chunk * 8) * 2, qs + pq * 1024);
+        else glds16_asm_soff_m0(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
+#endif
     }
 }
 template <int SP, int NW>
@@ -233,7 +238,11 @@ __device__ __forceinline__ void stage_image_asm(char* img, const bf16_t* src, in
     for (int pc = w; pc < SP / 8; pc += NW) {
         const int row = pc * 8 + r8;
         const int chunk = (lane & 7) ^ (row & 7);
+#ifdef KZV_ATT_M0_RESTORE
         glds16_asm(row < nvalid ? (const void*)(src + (int64_t)row * ld + chunk * 8) : zero16, img + pc * 1024);
+#else
+        glds16_asm_m0(row < nvalid ? (const void*)(src + (int64_t)row * ld + chunk * 8) : zero16, img + pc * 1024);
+#endif
     }
 }
 

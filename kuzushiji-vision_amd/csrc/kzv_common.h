@@ -187,6 +187,11 @@ __device__ __forceinline__ void glds16_asm_soff(const void* sbase, unsigned voff
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
 }
+// the SGPR-base form with M0 left clobbered (same condition as glds16_asm_m0)
+__device__ __forceinline__ void glds16_asm_soff_m0(const void* sbase, unsigned voff, void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
 __device__ __forceinline__ bf16x4 lds_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((KZV_LDS bf16x4*)p);
 }

@@ -383,7 +383,7 @@ def test_fit_steps_reduce_the_loss_and_eval_uses_running_statistics():
     assert all(np.isfinite(losses)) and losses[-1] < 0.6 * losses[0], losses[::6]
     m.eval()
     v1 = m.validation_step(batch, 0); v2 = m.validation_step(batch, 0)
-    assert v1 == v2 and np.isfinite(v1) and "val/total_loss" in m.logged
+    assert abs(v1 - v2) < 1e-6 and np.isfinite(v1) and "val/total_loss" in m.logged      # (the box loss is summed with float atomics)
     from kzv.ocr_data import decode_ctc_output
     out = m(batch["images"])
     dec = [decode_ctc_output(out["pred_logits"][i].cpu(), i2c, 0) for i in range(6)]

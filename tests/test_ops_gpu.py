@@ -164,7 +164,10 @@ def test_gemm_tn_large_outputs_take_the_256x256_kernel(lib, Mt, N, K):
                            dbias=db.data_ptr())
     L.check(lib.kzv_gemm_tn(C.byref(a), _st()), "gemm_tn")
     ref = Pm.float().t() @ Q.float() + base
-    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 2e-3      # fp32 sums of 4-8k products, split + atomics
+    # fp32 sums of 512-token splits; each split's partial tile crosses the workspace rounded to bf16 (2^-9 of ITS magnitude, a
+    # 1 / sqrt(splits) share of the sum; observed 0.7 - 1.7e-3 of the largest entry) -- the reference's autocast GEMM rounds the whole
+    # weight gradient to bf16 (4e-3)
+    assert (out - ref).abs().max().item() < 4e-3 * ref.abs().max().item() + 2e-3
     assert (db - db0 - Pm.float().sum(0)).abs().max().item() < 2e-3 * (Mt / 4096) ** 0.5 + 2e-3
     # the partial tiles are folded in a fixed order: bit-identical from run to run (a staging race would show up as
     # rare differing tiles)
