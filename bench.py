@@ -174,6 +174,12 @@ def main():
         os.environ["KZV_FORCE_DIST"] = "1"
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
 
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to stdout when its first communicator comes up, so
+    # for the whole run file descriptor 1 points at stderr and the result line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from kzv import _lib as L
     from kzv.config import vit_b_config, vit_l_config, vit_l_wide_config
@@ -326,7 +332,8 @@ def main():
             out["cpu_baseline"] = None
         if dp_reh is not None:
             out["dp_rehearsal"] = dp_reh
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
