@@ -117,16 +117,22 @@ def cpu_baseline(cfg, label_len, sample_batch, steps, budget_s=30.0):
         return time.perf_counter() - t0
 
     t_begin = time.perf_counter()
+
+    def sweep_threads(w):
+        out = {}
+        for n in sorted({min(16, all_threads), min(32, all_threads), all_threads}):
+            torch.set_num_threads(n)
+            out[n] = one_step(w)
+        return out
     w = make(sample_batch)
-    warm = one_step(w)                                        # warm-up (allocations, first-touch), all threads
-    if warm > budget_s / 5 and sample_batch > 8:              # would not fit: the stated fallback
+    one_step(w)                                               # warm-up (allocations, first touch: several times a steady step)
+    sweep = sweep_threads(w)
+    # the stated fallback: steady steps of batch 16 that would not leave room for two timed ones inside the budget -> batch 8
+    if sample_batch > 8 and (time.perf_counter() - t_begin) + 2 * min(sweep.values()) > budget_s:
         sample_batch = 8
         w = make(sample_batch)
-        warm = one_step(w)
-    sweep = {}
-    for n in sorted({min(16, all_threads), min(32, all_threads), all_threads}):
-        torch.set_num_threads(n)
-        sweep[n] = one_step(w)
+        one_step(w)
+        sweep = sweep_threads(w)
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     times = []

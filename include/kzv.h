@@ -283,7 +283,7 @@ int kzv_get_fp8(const kzv_model* m);
 int kzv_fp8_act_scales(const kzv_model* m, float* d_out, void* stream);
 
 /* OUT[N,K] (+)= P[Mtok,N]^T . Q[Mtok,K]   (weight gradient).  fp32 MFMA accumulation; small outputs add their token splits with
- * fp32 atomics, outputs of >= 24 tiles of 256 x 256 pass each split's partial tile through a workspace rounded to bf16 and fold them
+ * fp32 atomics, outputs of >= 9 tiles of 256 x 256 pass each split's partial tile through a workspace rounded to bf16 and fold them
  * in fp32 in a fixed order (bit-identical from run to run; error <= 2^-9 of a split's partial sum -- the reference's autocast GEMM
  * rounds the whole weight gradient to bf16). */
 typedef struct kzv_gemm_tn_args {

@@ -542,7 +542,7 @@ extern "C" int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream) {
     const int rc = tn_fill(a, p);
     if (rc != KZV_OK) return rc;
     KzvProfScope prof(1, 2.0 * a->Mtok * p.n_store * a->K, (hipStream_t)stream);
-    if (kzv_tn256_launch(p, (hipStream_t)stream)) return kzv_check_launch("gemm_tn");     // >= 24 tiles of 256x256: eight-phase kernel
+    if (kzv_tn256_launch(p, (hipStream_t)stream)) return kzv_check_launch("gemm_tn");     // >= 9 tiles of 256x256: eight-phase kernel
     const int blocks = tn_plan(p, tn_target());
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS); attr_done = true; }

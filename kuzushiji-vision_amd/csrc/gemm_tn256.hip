@@ -17,7 +17,7 @@
 //     workgroup is 62-66 MB per launch: as float atomics (~1 TB/s) that cost 70 us and ate the main-loop gain, so the
 //     partials are written with plain streaming stores (1-KiB row segments through LDS) into a workspace and a second
 //     small kernel folds the splits into OUT (reads 62 MB at HBM rate).
-// The launcher takes only shapes with >= 24 output tiles (qkv, fc1, fc2 of a ViT layer); everything else stays on the
+// The launcher takes only shapes with >= 9 output tiles (qkv, fc1, fc2, output projection of a ViT layer); everything else stays on the
 // 128x128 kernel with its atomic epilogue.
 //
 // Measured (MI355X, 41216 tokens): a reduction stage takes ~2.0 us here against 1.48 us for a K-tile of gemm_nt256 with the
@@ -296,7 +296,9 @@ float* tn_partials(size_t floats) {      // grow-only workspace (calls are strea
 
 int tn256_min_tiles() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("KZV_TN256_MIN_TILES"); v = e ? atoi(e) : 24; }
+    // 9: the 768 x 768 outputs (attention output projection, patch embedding) take this kernel too -- 28 token splits each,
+    // 83 -> ~70 us against the 128 x 128 kernel (-0.13 ms per step, same-box A/B; round 2's threshold was 24)
+    if (v < 0) { const char* e = getenv("KZV_TN256_MIN_TILES"); v = e ? atoi(e) : 9; }
     return v;
 }
 int device_cus() {

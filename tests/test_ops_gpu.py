@@ -151,7 +151,7 @@ def test_gemm_tn(lib, Mt, N, K):
 
 @pytest.mark.parametrize("Mt,N,K", [(8192, 1536, 1024), (4096, 2304, 768), (4160, 1288, 1280)])
 def test_gemm_tn_large_outputs_take_the_256x256_kernel(lib, Mt, N, K):
-    """>= 24 output tiles of 256x256 and Mtok % 64 == 0 -> gemm_tn256.hip (eight-phase schedule, token splits, atomics
+    """>= 9 output tiles of 256x256 and Mtok % 64 == 0 -> gemm_tn256.hip (eight-phase schedule, token splits, atomics
     epilogue, VALU bias sums); ragged N / K (clamped columns, guarded stores) in the last case; accumulates INTO out."""
     torch.manual_seed(Mt + N)
     Pm = torch.randn(Mt, N, device=DEV).bfloat16()
