@@ -206,30 +206,53 @@ __global__ __launch_bounds__(256, NKT <= 12 ? 3 : 2) void attn_fwd_kernel(const 
 // K and V images stay resident; Q and dO come in 32-query slabs through a 2-deep ring (the slab of block qb+1
 // is in flight during block qb); dS^T for the current slab only, as a [key][32 queries] image of 64-byte rows.
 constexpr int SLAB = 32 * 128;                  // 32 rows x 64 bf16
-constexpr int bwd_lds_bytes(int NKT) {
-    return ((NKT + 1) / 2 * 32) * 128 + NKT * 16 * 128 + 4 * SLAB + ((NKT + 1) / 2 * 32) * 64 + 3 * ((NKT + 1) / 2 * 32) * 4;
+// DS ("delta from the slab"): rowsum(dO . O) is computed per slab from the dO slab already in LDS and an O slab that rides
+// the same DMA (one more 4-KiB buffer), instead of from O and dO ROWS fetched a second time in the prologue: 59 instead of
+// 96 KB fetched before the first MFMA (the prologue is bound by what one CU can fetch, ~11 B per cycle).
+constexpr bool bwd_ds(int MODE, int NKT, int NW, bool EXACT) { return NW == 4 && (EXACT || (MODE == 1 && NKT <= 8)); }
+constexpr int bwd_lds_bytes(int NKT, int MODE, bool DS) {
+    return ((NKT + 1) / 2 * 32) * 128 + NKT * 16 * 128 + 4 * SLAB + ((NKT + 1) / 2 * 32) * 64 + (MODE == 1 ? 3 : 2) * ((NKT + 1) / 2 * 32) * 4 + (DS ? SLAB : 0);
 }
-static_assert(bwd_lds_bytes(12) <= 80 * 1024, "attention backward (<= 192 tokens) must fit two workgroups per CU");
+static_assert(bwd_lds_bytes(11, 0, true) <= 80 * 1024 && bwd_lds_bytes(12, 0, false) <= 80 * 1024 && bwd_lds_bytes(8, 1, true) <= 80 * 1024,
+              "attention backward (<= 192 tokens) must fit two workgroups per CU");
 
 // stage one 32-row slab of Q and of dO: 4 + 4 one-KiB pieces spread over the NW waves.  Rows past the last query are CLAMPED to
 // it, not zero-filled: their log-sum-exp is +inf, so P = dS = 0 there and the (finite) operand rows never reach a result; that
 // keeps the address a wave-uniform base + a 32-bit lane offset.
 template <int NW>
 __device__ __forceinline__ void stage_slabs(char* qs, char* os, const bf16_t* Qb, const bf16_t* dOb, unsigned ldq, unsigned ldo,
-                                            int row0, int nvalid, int w, int lane) {
-    for (int pc = w; pc < 8; pc += NW) {
+                                            int row0, int nvalid, int w, int lane, char* oo = nullptr, const bf16_t* Ob = nullptr) {
+    // pieces 0-3: Q, 4-7: dO, 8-11: O (DS only).  With 4 waves, wave w issues piece w of each: the 8 rows whose delta it reduces itself.
+    const int npc = oo ? 12 : 8;
+    for (int pc = w; pc < npc; pc += NW) {
         const int pq = pc & 3;
         const int row = pq * 8 + (lane >> 3);
         const unsigned chunk = (lane & 7) ^ (row & 7);
         const unsigned r = (unsigned)min(row0 + row, nvalid - 1);
 #ifdef KZV_ATT_M0_RESTORE
         if (pc < 4) glds16_asm_soff(Qb, (r * ldq + chunk * 8) * 2, qs + pq * 1024);
-        else glds16_asm_soff(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
+        else if (pc < 8) glds16_asm_soff(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
+        else glds16_asm_soff(Ob, (r * ldo + chunk * 8) * 2, oo + pq * 1024);
 #else       // every LDS-DMA of the backward kernel is issued from asm: M0 need not be handed back to the compiler
         if (pc < 4) glds16_asm_soff_m0(Qb, (r * ldq + chunk * 8) * 2, qs + pq * 1024);
-        else glds16_asm_soff_m0(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
+        else if (pc < 8) glds16_asm_soff_m0(dOb, (r * ldo + chunk * 8) * 2, os + pq * 1024);
+        else glds16_asm_soff_m0(Ob, (r * ldo + chunk * 8) * 2, oo + pq * 1024);
 #endif
     }
+}
+// delta' of the 8 rows this wave staged itself (rows 8w .. 8w+7 of the slab): lane = (row, 16-byte chunk); its own DMA pieces are
+// visible to it after its vmcnt wait, no barrier needed
+__device__ __forceinline__ void slab_delta(const char* os, const char* oo, float* dlt_slab, float keep_p, int w, int lane) {
+    const int row = w * 8 + (lane >> 3);
+    const unsigned off = row * 128 + ((((unsigned)lane & 7) ^ (row & 7)) << 4);
+    const bf16x8 a = *(const bf16x8*)(os + off), e = *(const bf16x8*)(oo + off);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)a[j]) * bf2f((bf16_t)e[j]);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if ((lane & 7) == 0) dlt_slab[row] = d * keep_p;
 }
 template <int SP, int NW>
 __device__ __forceinline__ void stage_image_asm(char* img, const bf16_t* src, int64_t ld, int nvalid, const void* zero16,
@@ -263,13 +286,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
     char* Ks = smem; char* Vs = Ks + SP * 128;
     char* Qring = Vs + NKT * 16 * 128; char* Oring = Qring + 2 * SLAB;
     char* dST = Oring + 2 * SLAB;                              // [SP keys][32 queries] bf16, 8-byte units swizzled by (key >> 1) & 7
+    constexpr bool DS = bwd_ds(MODE, NKT, NW, EXACT);
     float* lse = (float*)(dST + SP * 64);
     float* dlt = lse + SP;
-    int* kvalid = (int*)(dlt + SP);
+    char* Oo = (char*)(dlt + SP);                              // DS: the O slab (single buffer: consumed the moment it lands)
+    int* kvalid = (int*)(Oo + (DS ? SLAB : 0));                // MODE 1 only
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
     const bf16_t* Qb = p.Q + (int64_t)b * p.Sq * p.ldq + h * 64;
     const bf16_t* dOb = p.dO + (int64_t)b * p.Sq * p.ldo + h * 64;
+    const bf16_t* Ob = p.O + (int64_t)b * p.Sq * p.ldo + h * 64;
+    const float keep_p = 1.f / p.inv_keep;
+  if constexpr (DS) {
+    // log-sum-exp rows first (tracked loads: behind the asm DMAs the compiler's wait for them would cover the DMAs too)
+    float lv = INFINITY;
+    if (tid < SP && tid < p.Sq) lv = p.LSE[((int64_t)b * p.heads + h) * p.Sq + tid] * LOG2E;
+    stage_slabs<NW>(Qring, Oring, Qb, dOb, (unsigned)p.ldq, (unsigned)p.ldo, 0, p.Sq, w, lane, Oo, Ob);     // first: needed first
+    stage_image_asm<SP, NW>(Ks, p.K + (int64_t)b * p.Sk * p.ldk + h * 64, p.ldk, p.Sk, p.zero16, w, lane);
+    stage_image_asm<NKT * 16, NW>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
+    KZV_BSTAMP();
+    if (tid < SP) lse[tid] = lv;
+    for (int row = tid; row < SP; row += NT) if (row >= 32) dlt[row] = 0.f;      // rows past Sq of later slabs are written by slab_delta (finite, clamped rows)
+    KZV_BSTAMP();
+  } else {
     // log-sum-exp (in log2 units) and delta' = rowsum(dO . O) * P(keep) per query row: four lanes per row, 32 bytes each
     // (1 / P(keep) is taken out of dS and multiplied back into dQ / dK / dV at the very end).  Their loads are issued
     // FIRST and all at once -- vmcnt retires in order, so behind the image DMAs they would wait for all 46 KiB of them --
@@ -290,7 +329,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
     stage_image_asm<NKT * 16, NW>(Vs, p.V + (int64_t)b * p.Sk * p.ldv + h * 64, p.ldv, p.Sk, p.zero16, w, lane);
     stage_slabs<NW>(Qring, Oring, Qb, dOb, (unsigned)p.ldq, (unsigned)p.ldo, 0, p.Sq, w, lane);
     KZV_BSTAMP();
-    const float keep_p = 1.f / p.inv_keep;
 #pragma unroll
     for (int i = 0; i < DR; ++i) {
         const int row = (tid >> 2) + i * (NT / 4);
@@ -307,10 +345,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         }
     }
     KZV_BSTAMP();
+  }
     if (MODE == 1)
         for (int row = tid; row < SP; row += NT) kvalid[row] = row < p.Sk && p.ids[(int64_t)b * p.ld_ids + row] != p.pad_id;
     for (int i = tid; i < SP * 64 / 16; i += NT) ((uint4*)dST)[i] = make_uint4(0, 0, 0, 0);   // key rows no wave writes stay 0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (DS) slab_delta(Oring, Oo, dlt, keep_p, w, lane);
     __syncthreads();
     KZV_BSTAMP();
 
@@ -352,7 +392,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
         }
         // the next slab flies during this block's two phases; its (slow to issue) DMAs go out behind the LDS reads above
         if (qb + 1 < nqb)
-            stage_slabs<NW>(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, (unsigned)p.ldq, (unsigned)p.ldo, (qb + 1) * 32, p.Sq, w, lane);
+            stage_slabs<NW>(Qring + ((qb + 1) & 1) * SLAB, Oring + ((qb + 1) & 1) * SLAB, Qb, dOb, (unsigned)p.ldq, (unsigned)p.ldo, (qb + 1) * 32, p.Sq, w, lane,
+                            DS ? Oo : nullptr, Ob);
         KZV_BSTAMP();
 #pragma unroll
         for (int a = 0; a < TPW; ++a) {
@@ -445,6 +486,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_kernel(const AttnP p) {
             // The next slab (this wave's pieces, issued a whole block ago) has landed.  The wait sits BEFORE the dQ
             // stores: vmcnt retires in issue order, so after them it would also wait for stores issued a moment ago.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (DS)      // delta' of the next slab's rows this wave staged (published by the barrier below)
+                if (qb + 1 < nqb) slab_delta(Oring + ((qb + 1) & 1) * SLAB, Oo, dlt + (qb + 1) * 32, keep_p, w, lane);
             if (q < p.Sq) {
                 const float osc = p.scale * p.inv_keep;
                 bf16_t* row = p.dQ + ((int64_t)b * p.Sq + q) * p.ldq + h * 64 + 4 * g;
@@ -516,9 +559,10 @@ static void launch_fwd(const AttnP& p, int blocks, hipStream_t s) {
 }
 template <int MODE, int NKT, int NW, bool EXACT>
 static void launch_bwd(const AttnP& p, int blocks, hipStream_t s) {
+    constexpr int lds = bwd_lds_bytes(NKT, MODE, bwd_ds(MODE, NKT, NW, EXACT));
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<MODE, NKT, NW, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(NKT)); attr = true; }
-    hipLaunchKernelGGL((attn_bwd_kernel<MODE, NKT, NW, EXACT>), dim3(blocks), dim3(NW * 64), bwd_lds_bytes(NKT), s, p);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<MODE, NKT, NW, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((attn_bwd_kernel<MODE, NKT, NW, EXACT>), dim3(blocks), dim3(NW * 64), lds, s, p);
 }
 
 extern "C" int kzv_attn_fwd(const kzv_attn_args* a, void* stream) {
@@ -555,7 +599,8 @@ extern "C" int kzv_attn_bwd(const kzv_attn_args* a, void* stream) {
     const int nkt = (a->Sk + 15) >> 4, nqb = (a->Sq + 31) >> 5, blocks = a->B * a->heads;
     KzvProfScope prof(3, 10.0 * a->B * a->heads * (double)a->Sq * a->Sk * 64, s);
     // the per-row arrays (log-sum-exp, delta) hold 32 * ceil(NKT / 2) queries: 192 for every <= 12-tile instance
-    if (a->mode == 1) launch_bwd<1, 12, 4, false>(p, blocks, s);
+    if (a->mode == 1 && nkt <= 8) launch_bwd<1, 8, 4, false>(p, blocks, s);           // the decoder (<= 128 positions)
+    else if (a->mode == 1) launch_bwd<1, 12, 4, false>(p, blocks, s);
     else if (nkt == 11 && nqb <= 6) launch_bwd<0, 11, 4, true>(p, blocks, s);
     else if (nkt == 10 && nqb <= 5) launch_bwd<0, 10, 4, true>(p, blocks, s);
     else if (nkt <= 12 && nqb <= 6) launch_bwd<0, 12, 4, false>(p, blocks, s);

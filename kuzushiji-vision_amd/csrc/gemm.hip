@@ -427,7 +427,9 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     static int use_p = -1;
     if (use_p < 0) { const char* e = getenv("KZV_NT256P"); use_p = e ? atoi(e) : 1; }
     if (kzv_rows_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");      // M <= 1024: the generation step's GEMMs
-    const bool two_store = epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32;
+    static int p_gelu = -1;      // dev knob: the two-store GELU epilogues on the persistent kernel too (A/B; default off)
+    if (p_gelu < 0) { const char* e = getenv("KZV_NT256P_GELU"); p_gelu = e ? atoi(e) : 0; }
+    const bool two_store = !p_gelu && (epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32);
     if (use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
     if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
 #define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \
