@@ -63,6 +63,9 @@ __global__ void embed_assemble_kernel(const float* __restrict__ pe, const float*
     ((float4*)(x0 + row * He))[c] = make_float4(o0, o1, o2, o3);
 }
 
+// (Round 3 tried to parallelise this pass over the batch -- slices of the batch per thread, strips of positions, 4 - 8 loads in flight,
+// atomics for the sums: 126 - 289 us against 147 us for this form, whose one-writer sums are also bit-reproducible.  Not the loads:
+// the float atomics of many adders on the 768 bias addresses.)
 // thread = (s, 4 columns): loops over the batch; writes dpatch (bf16), dpos (+= sum_b), dcls, patch-bias grad.
 __global__ void embed_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t* __restrict__ dpatch, float* dcls,
                                           float* dpos, float* dpbias, int B, int np, int He, unsigned thr16,
@@ -204,6 +207,72 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const float* __r
 // one workgroup per token row; target = labels[b][t+1]; rows whose target is pad contribute nothing and
 // get a zero dlogits row.  dlogits = (softmax - onehot) / count, bf16, pad columns [V, ldl) zeroed.
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ labels,
+                                                 int L, int T, int V, int pad, const float* __restrict__ count,
+                                                 float* loss, bf16_t* __restrict__ dlogits) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = row / T, t = row - b * T;
+    const int64_t tgt = labels[(int64_t)b * L + t + 1];
+    const float* lr = logits + (int64_t)row * ldl;
+    bf16_t* dr = dlogits ? dlogits + (int64_t)row * ldl : nullptr;
+    const int n4 = (int)(ldl / 4);
+    if (tgt == pad) {
+        if (dr) for (int i = tid; i < n4; i += 256) ((uint2*)dr)[i] = make_uint2(0, 0);
+        return;
+    }
+    // the row lives in registers (ldl / 4 <= 256 * RV float4 pieces): read once, 16 bytes per lane
+    constexpr int RV = 5;                                  // 5 * 256 * 4 = 5120 columns
+    float4 v[RV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < RV; ++j) {
+        const int i = tid + j * 256;
+        v[j] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (i < n4) {
+            v[j] = ((const float4*)lr)[i];
+            if (4 * i + 1 > V) v[j].x = -INFINITY;      // pad columns [V, ldl) hold zeros, not logits
+            if (4 * i + 2 > V) v[j].y = -INFINITY;
+            if (4 * i + 3 > V) v[j].z = -INFINITY;
+            if (4 * i + 4 > V) v[j].w = -INFINITY;
+        }
+        mx = fmaxf(fmaxf(mx, fmaxf(v[j].x, v[j].y)), fmaxf(v[j].z, v[j].w));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < RV; ++j) {
+        v[j].x = __expf(v[j].x - mx); v[j].y = __expf(v[j].y - mx); v[j].z = __expf(v[j].z - mx); v[j].w = __expf(v[j].w - mx);
+        se += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    se = wave_sum(se);
+    if (lane == 0) red[4 + w] = se;
+    __syncthreads();
+    se = red[4] + red[5] + red[6] + red[7];
+    const float lse = mx + __logf(se);
+    const float inv_cnt = 1.f / *count;
+    if (tid == 0) atomicAdd(loss, (lse - lr[tgt]) * inv_cnt);
+    if (dr) {
+        const float sc = inv_cnt / se;                     // softmax = exp(x - mx) / se
+#pragma unroll
+        for (int j = 0; j < RV; ++j) {
+            const int i = tid + j * 256;
+            if (i < n4) {
+                float o[4] = {v[j].x * sc, v[j].y * sc, v[j].z * sc, v[j].w * sc};
+                const int64_t d = tgt - 4 * (int64_t)i;
+                if (d >= 0 && d < 4) o[d] -= inv_cnt;
+                ((uint2*)dr)[i] = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+}
+
+// the same for rows wider than the registers of ce_kernel hold (> 5120 columns): three passes over the (L2-resident) row
+// one workgroup per token row; target = labels[b][t+1]; rows whose target is pad contribute nothing and
+// get a zero dlogits row.  dlogits = (softmax - onehot) / count, bf16, pad columns [V, ldl) zeroed.
+__global__ __launch_bounds__(256) void ce_generic_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ labels,
                                                  int L, int T, int V, int pad, const float* __restrict__ count,
                                                  float* loss, bf16_t* __restrict__ dlogits) {
     __shared__ float red[8];
@@ -439,7 +508,8 @@ int kzv_embed_scatter_bwd(const float* dsum, const int64_t* labels, int L, const
 int kzv_ce_fwd_bwd(const float* logits, int64_t ldl, const int64_t* labels, int L, int B, int T, int V, int pad,
                    const float* count, float* loss, bf16_t* dlogits, hipStream_t s) {
     if (ldl % 4) return kzv_fail(KZV_E_ARG, "ce: ldl %% 4");
-    hipLaunchKernelGGL(ce_kernel, dim3(B * T), dim3(256), 0, s, logits, ldl, labels, L, T, V, pad, count, loss, dlogits);
+    if (ldl <= 5120) hipLaunchKernelGGL(ce_kernel, dim3(B * T), dim3(256), 0, s, logits, ldl, labels, L, T, V, pad, count, loss, dlogits);
+    else hipLaunchKernelGGL(ce_generic_kernel, dim3(B * T), dim3(256), 0, s, logits, ldl, labels, L, T, V, pad, count, loss, dlogits);
     return kzv_check_launch("ce_fwd_bwd");
 }
 

@@ -299,6 +299,7 @@ def test_kv_cached_step_equals_the_prefix_recompute(tmp_path, wide):
     (2, 12, dict(image_h=16, image_w=16)),                   # a single patch (+ CLS)
     (2, 12, dict(enc_layers=1, dec_layers=1)),
     (300, 9, {}),                                            # batch larger than the bench's
+    (3, 10, dict(vocab=5200)),                               # logits rows wider than the register-resident CE kernel holds (> 5120 columns)
 ])
 def test_edge_geometries_match_oracle(tmp_path, B, L, kw):
     import dataclasses
