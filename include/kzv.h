@@ -339,13 +339,16 @@ int kzv_ocr_conv_weight(const float* w, void* wp_bf16, void* wpT_bf16, int Cout,
 int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, int Cin, int KH, int KW, int Kp, void* stream);
 /* nn.BatchNorm2d (+ the BasicBlock's residual add and ReLU): out bf16 = [relu](gamma * (y - mean) * rstd + beta [+ resid]); y fp32
  * [M, C].  train: batch statistics (biased variance), running statistics updated with `momentum` and the unbiased variance;
- * eval: the running statistics.  mean / rstd [C] are kept for the backward.  d_scratch: 2 * C floats. */
+ * eval: the running statistics.  mean / rstd [C] are kept for the backward.  d_scratch: kzv_ocr_bn_scratch_floats(M, C) floats.
+ * The statistics (and the backward's dgamma / dbeta) are reduced in a fixed order, without atomics: a one-ulp difference of a mean
+ * flips the bf16 rounding of an activation and, through ReLU masks, ~1 % of the gradients downstream. */
+int64_t kzv_ocr_bn_scratch_floats(int64_t M, int C);
 int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
                    float* rstd, const void* resid_bf16, void* out_bf16, int relu, int train, float eps, float momentum, float* d_scratch, void* stream);
 /* its backward: da fp32 [M, C] = gradient of the (post-ReLU) output; dz fp32 = da masked by the ReLU (also the gradient of the
- * residual input); dgamma / dbeta must arrive ZEROED (they are needed complete by the second pass); dy bf16 = gradient of y. */
+ * residual input); dgamma / dbeta are accumulated into (+=); dy bf16 = gradient of y.  d_scratch as for the forward. */
 int kzv_ocr_bn_bwd(const float* da, const void* a_bf16, const float* y, int64_t M, int C, const float* mean, const float* rstd, const float* gamma,
-                   float* dz, float* dgamma, float* dbeta, void* dy_bf16, int relu, int train, void* stream);
+                   float* dz, float* dgamma, float* dbeta, void* dy_bf16, int relu, int train, float* d_scratch, void* stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem, NHWC bf16; idx = winning tap per output (first maximum, like torch) */
 int kzv_ocr_maxpool_fwd(const void* x_bf16, void* out_bf16, unsigned char* idx, int N, int H, int W, int C, void* stream);
 int kzv_ocr_maxpool_bwd(const float* dout, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);

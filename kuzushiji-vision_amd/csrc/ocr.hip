@@ -111,8 +111,8 @@ __global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gp, float* __
 
 // ---------------------------------------------------------------------------------------------- BatchNorm2d
 // per-channel sums over the rows of y fp32 [M, C]: pass 0 -> sum(y), pass 1 -> sum((y - mean)^2) with mean = sum0 / M.
-// Block = 256 threads = 64 channel-quads... one thread per (row slice, 4 channels); partials meet through LDS, one atomic per
-// (block, channel).
+// One thread per (row slice, 4 channels); a block's partials meet through LDS and go to row blockIdx.x of `out` [blocks, C];
+// bn_partial_sum_kernel adds the rows in order (bit-reproducible statistics).
 __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ sum0,
                                                         float* __restrict__ out, int centered, int rows_per_block) {
     __shared__ float red[256 * 4];
@@ -133,13 +133,20 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
         }
         *(f32x4*)(red + threadIdx.x * 4) = acc;
         __syncthreads();
-        if (slice == 0 && cb + cq < c4n) {
-            for (int s2 = 1; s2 < tpc; ++s2) acc += *(const f32x4*)(red + (s2 * min(c4n, 256) + cq) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(out + c + j, acc[j]);
+        if (slice == 0 && cb + cq < c4n) {      // this block's partial row: summed in a FIXED order by the finalize kernel (no atomics:
+            for (int s2 = 1; s2 < tpc; ++s2) acc += *(const f32x4*)(red + (s2 * min(c4n, 256) + cq) * 4);     // a one-ulp difference of a
+            *(f32x4*)(out + (int64_t)blockIdx.x * C + c) = acc;                    // mean flips bf16 roundings of the activations downstream)
         }
         __syncthreads();
     }
+}
+// tot[c] = sum over the `rows` partial rows of part [rows, C], in row order
+__global__ void bn_partial_sum_kernel(const float* __restrict__ part, float* __restrict__ tot, int rows, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += part[(int64_t)r * C + c];
+    tot[c] = s;
 }
 // mean / rstd from the two sums (train) or from the running statistics (eval); train also updates the running statistics the
 // way nn.BatchNorm2d does (momentum 0.1, UNBIASED variance into running_var)
@@ -208,9 +215,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     __syncthreads();
     if (slice == 0 && cq < c4n) {
         for (int s2 = 1; s2 < tpc; ++s2) { sg += *(const f32x4*)(red + (s2 * nq + cq) * 8); sb += *(const f32x4*)(red + (s2 * nq + cq) * 8 + 4); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { atomicAdd(dgamma + c + j, sg[j]); atomicAdd(dbeta + c + j, sb[j]); }
+        *(f32x4*)(dgamma + (int64_t)blockIdx.x * C + c) = sg;       // partial rows [blocks, C] (dgamma / dbeta here = scratch)
+        *(f32x4*)(dbeta + (int64_t)blockIdx.x * C + c) = sb;
     }
+}
+// totals of this launch (read by the second pass) and their accumulation into the gradient buffers
+__global__ void bn_bwd_totals_kernel(const float* __restrict__ pg, const float* __restrict__ pb, float* __restrict__ tot, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int rows, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, b = 0.f;
+    for (int r = 0; r < rows; ++r) { g += pg[(int64_t)r * C + c]; b += pb[(int64_t)r * C + c]; }
+    tot[c] = g; tot[C + c] = b;
+    dgamma[c] += g; dbeta[c] += b;
 }
 // pass 2: dy = gamma * rstd * (dz - dbeta / M - xhat * dgamma / M) (train) or gamma * rstd * dz (eval) -> bf16 (GEMM operand)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ mean,
@@ -508,7 +525,8 @@ extern "C" int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, in
     hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(nblk((int64_t)Cout * Cin * KH * KW, 256)), dim3(256), 0, (hipStream_t)stream, gp, g, Cout, Cin, KH, KW, Kp);
     return kzv_check_launch("ocr_conv_wgrad_unpack");
 }
-// d_scratch: 2 * C floats
+// d_scratch: kzv_ocr_bn_scratch_floats(M, C) floats
+extern "C" int64_t kzv_ocr_bn_scratch_floats(int64_t M, int C) { return (2 * (int64_t)nblk(M, 256) + 2) * C; }
 extern "C" int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var,
                               float* mean, float* rstd, const void* resid_bf16, void* out_bf16, int relu, int train, float eps, float momentum,
                               float* d_scratch, void* stream) {
@@ -517,24 +535,28 @@ extern "C" int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gam
     hipStream_t s = (hipStream_t)stream;
     if (train) {
         KZV_OCR_NULL(!d_scratch, "ocr_bn_fwd: scratch");
-        if (hipMemsetAsync(d_scratch, 0, sizeof(float) * 2 * C, s) != hipSuccess) return kzv_fail(KZV_E_HIP, "ocr_bn_fwd: memset");
-        const int rpb = 256;
-        hipLaunchKernelGGL(bn_colsum_kernel, dim3(nblk(M, rpb)), dim3(256), 0, s, y, M, C, nullptr, d_scratch, 0, rpb);
-        hipLaunchKernelGGL(bn_colsum_kernel, dim3(nblk(M, rpb)), dim3(256), 0, s, y, M, C, d_scratch, d_scratch + C, 1, rpb);
+        const int rpb = 256, nb = (int)nblk(M, rpb);
+        float* part = d_scratch + 2 * C;                       // [nb, C] partial rows, reused by both passes
+        hipLaunchKernelGGL(bn_colsum_kernel, dim3(nb), dim3(256), 0, s, y, M, C, nullptr, part, 0, rpb);
+        hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, part, d_scratch, nb, C);
+        hipLaunchKernelGGL(bn_colsum_kernel, dim3(nb), dim3(256), 0, s, y, M, C, d_scratch, part, 1, rpb);
+        hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, part, d_scratch + C, nb, C);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, d_scratch, d_scratch ? d_scratch + C : nullptr, mean, rstd, run_mean, run_var, C, M, eps, momentum, train);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), 0, s, y, mean, rstd, gamma, beta, (const bf16_t*)resid_bf16, (bf16_t*)out_bf16, M, C, relu);
     return kzv_check_launch("ocr_bn_fwd");
 }
 extern "C" int kzv_ocr_bn_bwd(const float* da, const void* a_bf16, const float* y, int64_t M, int C, const float* mean, const float* rstd,
-                              const float* gamma, float* dz, float* dgamma, float* dbeta, void* dy_bf16, int relu, int train, void* stream) {
-    KZV_OCR_NULL(!da || !y || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || !dy_bf16 || (relu && !a_bf16) || C % 4 || C > 1024, "ocr_bn_bwd: bad argument");
+                              const float* gamma, float* dz, float* dgamma, float* dbeta, void* dy_bf16, int relu, int train, float* d_scratch,
+                              void* stream) {
+    KZV_OCR_NULL(!da || !y || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || !dy_bf16 || !d_scratch || (relu && !a_bf16) || C % 4 || C > 1024, "ocr_bn_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = 256;
-    // dgamma / dbeta of THIS launch are needed by pass 2: reduce into zeroed scratch rows at the tail of dz? -- no: the caller passes
-    // zeroed dgamma / dbeta (the gradient buffers are zeroed once per step and each BatchNorm is used once per step)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk(M, rpb)), dim3(256), 0, s, da, (const bf16_t*)a_bf16, y, mean, rstd, dz, dgamma, dbeta, M, C, relu, rpb);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), 0, s, dz, y, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dy_bf16, M, C, train);
+    const int rpb = 256, nb = (int)nblk(M, rpb);
+    float* tot = d_scratch;                                    // [2, C]: this launch's dgamma | dbeta (the second pass needs them complete)
+    float* pg = d_scratch + 2 * C; float* pb = pg + (int64_t)nb * C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, s, da, (const bf16_t*)a_bf16, y, mean, rstd, dz, pg, pb, M, C, relu, rpb);
+    hipLaunchKernelGGL(bn_bwd_totals_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, pg, pb, tot, dgamma, dbeta, nb, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), 0, s, dz, y, mean, rstd, gamma, tot, tot + C, (bf16_t*)dy_bf16, M, C, train);
     return kzv_check_launch("ocr_bn_bwd");
 }
 extern "C" int kzv_ocr_maxpool_fwd(const void* x, void* out, unsigned char* idx, int N, int H, int W, int C, void* stream) {

@@ -118,19 +118,24 @@ def decode_ctc_output(logits, idx_to_char, blank_idx):
 class OcrLoader:
     """DataLoader(dataset, batch_size, shuffle, collate_fn=ocr_collate_fn) of ocr_lightning/train.py:65-82, single process."""
 
-    def __init__(self, dataset, batch_size, shuffle=False, seed=0):
+    def __init__(self, dataset, batch_size, shuffle=False, seed=0, rank=0, world=1):
         self.dataset, self.batch_size, self.shuffle, self.seed, self.epoch = dataset, batch_size, shuffle, seed, 0
+        self.rank, self.world = rank, world                 # DistributedSampler: every rank takes each world-th sample of the epoch's order
 
     def set_epoch(self, epoch):
         self.epoch = epoch
 
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        n = (len(self.dataset) + self.world - 1) // self.world
+        return (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         import random
         order = list(range(len(self.dataset)))
         if self.shuffle:
             random.Random(self.seed * 7919 + self.epoch).shuffle(order)
+        if self.world > 1:                                   # padded to equal length like DistributedSampler (drop_last=False)
+            total = (len(order) + self.world - 1) // self.world * self.world
+            order = (order + order[:total - len(order)])[self.rank::self.world]
         for i in range(0, len(order), self.batch_size):
             yield ocr_collate_fn([self.dataset[j] for j in order[i:i + self.batch_size]])

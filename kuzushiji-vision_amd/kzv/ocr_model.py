@@ -242,7 +242,7 @@ class OCRModel:
         self._gemm_nt(cols, self._w16[c.conv_key], y, M, c.cout, c.Kp, L.EPI_F32)
         mean, rstd = torch.empty(c.cout, device=dev), torch.empty(c.cout, device=dev)
         out = torch.empty(M, c.cout, dtype=torch.bfloat16, device=dev)
-        scratch = torch.empty(2 * c.cout, device=dev)
+        scratch = torch.empty(lib.kzv_ocr_bn_scratch_floats(M, c.cout), device=dev)
         L.check(lib.kzv_ocr_bn_fwd(y.data_ptr(), M, c.cout, self.param(c.bn_key + ".weight").data_ptr(), self.param(c.bn_key + ".bias").data_ptr(),
                                    self.buffers[c.bn_key + ".running_mean"].data_ptr(), self.buffers[c.bn_key + ".running_var"].data_ptr(),
                                    mean.data_ptr(), rstd.data_ptr(), L.ptr(resid16), out.data_ptr(), int(relu), int(self.training), BN_EPS, BN_MOMENTUM,
@@ -485,11 +485,11 @@ class OCRModel:
         M, dev = k["y"].shape[0], self.device
         dz = torch.empty(M, c.cout, device=dev)
         dy = torch.empty(M, c.cout, dtype=torch.bfloat16, device=dev)
-        # every BatchNorm runs once per step and zero_grad() precedes the step, so its gradient entries are still zero here --
-        # which kzv_ocr_bn_bwd needs (its second pass reads the complete sums)
+        scratch = torch.empty(self.lib.kzv_ocr_bn_scratch_floats(M, c.cout), device=dev)
         L.check(self.lib.kzv_ocr_bn_bwd(da.data_ptr(), k["out"].data_ptr(), k["y"].data_ptr(), M, c.cout, k["mean"].data_ptr(), k["rstd"].data_ptr(),
                                         self.param(c.bn_key + ".weight").data_ptr(), dz.data_ptr(), self.grad(c.bn_key + ".weight").data_ptr(),
-                                        self.grad(c.bn_key + ".bias").data_ptr(), dy.data_ptr(), int(k["relu"]), int(self.training), L.stream_handle()), "bn_bwd")
+                                        self.grad(c.bn_key + ".bias").data_ptr(), dy.data_ptr(), int(k["relu"]), int(self.training), scratch.data_ptr(),
+                                        L.stream_handle()), "bn_bwd")
         return dz, dy
 
     def _to16(self, x32):
@@ -530,10 +530,24 @@ class OCRModel:
         self.sync_weights()
 
     def fit_step(self, batch, batch_idx=0):
-        """One optimisation step the way Lightning drives the reference: zero_grad, training_step, backward, Adam."""
+        """One optimisation step the way Lightning drives the reference: zero_grad, training_step, backward, [DDP gradient mean when
+        a process group is up: pl.Trainer(devices=N) of ocr_lightning/train.py:132-140 -- one all-reduce of the flat gradient buffer,
+        BatchNorm statistics stay per rank as in plain DDP], Adam."""
         self.train()
         self.zero_grad()
         loss = self.training_step(batch, batch_idx)
         self.backward()
+        self.allreduce_grads()
         self.optimizer_step()
         return loss
+
+    def allreduce_grads(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM)
+            else:                                             # gloo rehearsal: through host memory
+                g = self.flat_grads.cpu()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                self.flat_grads.copy_(g.to(self.device))
+            self.flat_grads.mul_(1.0 / dist.get_world_size())

@@ -86,6 +86,9 @@ def main_ocr(args):
         raise SystemExit("--model ocr needs --train_data_dir and --val_data_dir (ocr_lightning/train.py:163-164)")
     if args.accelerator not in ("gpu", "auto"):
         raise SystemExit("this engine runs on MI355X GPUs only")
+    from .trainer import init_distributed
+    rank, world, local = init_distributed()              # one process per GPU (torch.distributed.run), as for the TrOCR path
+    torch.cuda.set_device(local)
     torch.manual_seed(args.seed)
     os.makedirs(args.checkpoint_dir, exist_ok=True); os.makedirs(args.log_dir, exist_ok=True)
     train_ds = OcrDataset(args.train_data_dir, char_to_idx=CHAR_TO_IDX)
@@ -93,12 +96,12 @@ def main_ocr(args):
     if len(train_ds) == 0:
         print(f"Error: Training dataset at {args.train_data_dir} is empty. Please check the path and data structure.")
         return None
-    train_loader = OcrLoader(train_ds, args.batch_size, shuffle=True, seed=args.seed)
+    train_loader = OcrLoader(train_ds, args.batch_size, shuffle=True, seed=args.seed, rank=rank, world=world)
     val_loader = OcrLoader(val_ds, args.batch_size) if len(val_ds) else None
-    model = OCRModel(CHAR_TO_IDX, IDX_TO_CHAR, learning_rate=args.learning_rate, max_boxes=args.max_boxes, init_seed=args.seed)
+    model = OCRModel(CHAR_TO_IDX, IDX_TO_CHAR, learning_rate=args.learning_rate, max_boxes=args.max_boxes, init_seed=args.seed, device=f"cuda:{local}")
     model.configure_optimizers()
-    best, best_path, bad, hist = float("inf"), None, 0, []
-    log = open(os.path.join(args.log_dir, "metrics.jsonl"), "a", encoding="utf-8")
+    state, hist = {"best": float("inf"), "best_path": None, "bad": 0}, []
+    log = open(os.path.join(args.log_dir, "metrics.jsonl") if rank == 0 else os.devnull, "a", encoding="utf-8")
     for epoch in range(args.epochs):
         train_loader.set_epoch(epoch)
         model.logged.clear()
@@ -111,27 +114,50 @@ def main_ocr(args):
                 model.validation_step(batch, i)
             rec.update({k: sum(v) / len(v) for k, v in model.logged.items() if k.startswith("val/")})
             model.train()
-        hist.append(rec); log.write(json.dumps(rec) + "\n"); log.flush()
-        print(" ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()))
-        torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch},
-                   os.path.join(args.checkpoint_dir, "last.ckpt"))
-        vl = rec.get("val/total_loss")
-        if vl is not None:
-            if vl < best:
-                best, bad = vl, 0
-                if best_path and os.path.exists(best_path):
-                    os.remove(best_path)
-                best_path = os.path.join(args.checkpoint_dir, f"ocr-epoch={epoch:02d}-val_total_loss={vl:.2f}.ckpt")
-                torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch}, best_path)
-            else:
-                bad += 1
-                if bad >= args.patience:
-                    print(f"Early stopping: val/total_loss has not improved for {bad} epochs")
-                    break
+        hist.append(rec)
+        stop = [False]
+        if rank == 0:
+            stop[0] = _ocr_epoch_end(args, model, rec, epoch, log, state)
+        if world > 1:                                        # every rank leaves the loop together (rank 0 monitors val/total_loss)
+            torch.distributed.broadcast_object_list(stop, src=0)
+        if stop[0]:
+            break
     log.close()
-    print(f"Training finished.\nBest model checkpoint saved at: {best_path}" if best_path else "No best model checkpoint was saved.")
+    best_path = state["best_path"]
+    if rank == 0:
+        print(f"Training finished.\nBest model checkpoint saved at: {best_path}" if best_path else "No best model checkpoint was saved.")
     main_ocr.best_model_path = best_path
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     return hist
+
+
+def _ocr_epoch_end(args, model, rec, epoch, log, state):
+    """rank 0: metrics line, last.ckpt, ModelCheckpoint(monitor val/total_loss, save_top_k=1), EarlyStopping(patience) -> stop?"""
+    import json
+    import torch
+    best, best_path, bad = state["best"], state["best_path"], state["bad"]
+    log.write(json.dumps(rec) + "\n"); log.flush()
+    print(" ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()))
+    torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch},
+               os.path.join(args.checkpoint_dir, "last.ckpt"))
+    vl = rec.get("val/total_loss")
+    if vl is not None:
+        if vl < best:
+            best, bad = vl, 0
+            if best_path and os.path.exists(best_path):
+                os.remove(best_path)
+            best_path = os.path.join(args.checkpoint_dir, f"ocr-epoch={epoch:02d}-val_total_loss={vl:.2f}.ckpt")
+            torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch}, best_path)
+        else:
+            bad += 1
+            if bad >= args.patience:
+                print(f"Early stopping: val/total_loss has not improved for {bad} epochs")
+                state.update(best=best, best_path=best_path, bad=bad)
+                return True
+    state.update(best=best, best_path=best_path, bad=bad)
+    return False
 
 
 def main(argv=None):

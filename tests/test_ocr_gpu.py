@@ -203,7 +203,7 @@ def test_batchnorm_relu_residual_forward_backward(lib, train, relu, resid):
     mean, rstd = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
     out = torch.empty(M, Cc, dtype=torch.bfloat16, device=DEV)
     r16 = nh(r).to(torch.bfloat16).to(DEV) if resid else None
-    gam, bet, scr = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), torch.empty(2 * Cc, device=DEV)
+    gam, bet, scr = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), torch.empty(lib.kzv_ocr_bn_scratch_floats(M, Cc), device=DEV)
     L.check(lib.kzv_ocr_bn_fwd(yd.data_ptr(), M, Cc, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                mean.data_ptr(), rstd.data_ptr(), L.ptr(r16), out.data_ptr(), relu, train, 1e-5, 0.1, scr.data_ptr(), _st()), "bn")
     assert (out.float().cpu() - nh(a)).abs().max() < 1e-2 * max(1.0, a.abs().max().item())                # bf16 output
@@ -213,7 +213,7 @@ def test_batchnorm_relu_residual_forward_backward(lib, train, relu, resid):
     dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
     dad = nh(da).to(DEV)
     L.check(lib.kzv_ocr_bn_bwd(dad.data_ptr(), out.data_ptr(), yd.data_ptr(), M, Cc, mean.data_ptr(), rstd.data_ptr(),
-                               gam.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(), dy.data_ptr(), relu, train, _st()), "bn_bwd")
+                               gam.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(), dy.data_ptr(), relu, train, scr.data_ptr(), _st()), "bn_bwd")
     if train:
         assert (dg.cpu() - bn.weight.grad).abs().max() < 2e-3 * max(1.0, bn.weight.grad.abs().max().item())
         assert (db.cpu() - bn.bias.grad).abs().max() < 2e-3 * max(1.0, bn.bias.grad.abs().max().item())
@@ -417,3 +417,45 @@ def test_cli_trains_the_ocr_model_on_a_folder_dataset(tmp_path):
     assert "feature_extractor.7.2.bn2.running_var" in ck["state_dict"] and ck["hyper_parameters"]["max_boxes"] == 5
     m = OCRModel(CHAR_TO_IDX, IDX_TO_CHAR, max_boxes=5)
     m.load_state_dict(ck["state_dict"], strict=True)
+
+
+def test_two_rank_data_parallel_fit_steps(tmp_path):
+    """pl.Trainer(devices=2) for this model = DDP: each rank its own shard and its own BatchNorm statistics, gradients averaged
+    before Adam.  Two ranks of the real fit_step on one GPU over gloo: identical replicas afterwards, equal (to float-atomic order) to
+    one process that computes the two shards' gradients one after the other and averages them by hand."""
+    import socket
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _ocr_ddp_worker as W
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   KZV_DIST_BACKEND="gloo", KZV_FORCE_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ocr_ddp_worker.py"), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    r0, r1 = (torch.load(tmp_path / f"ocr_rank{r}.pt")["params"] for r in range(2))
+    assert torch.equal(r0, r1)
+    m = W.make()
+    init = m.flat_params.clone()
+    for step in range(W.STEPS):
+        acc = torch.zeros_like(m.flat_grads)
+        for rank in range(2):
+            m.train(); m.zero_grad()
+            m.training_step(W.shard(step, rank, 2), step)
+            m.backward()
+            acc += m.flat_grads
+        m.flat_grads.copy_(acc / 2)
+        m.optimizer_step()
+    torch.cuda.synchronize()
+    # The forward is bit-reproducible (BatchNorm statistics are reduced in a fixed order); what is left between the two runs is the
+    # summation order of the weight-gradient split-K atomics and of the all-reduce, which Adam can turn into a +-lr difference only
+    # where a gradient element is ~0.  Compare the UPDATE as a whole.
+    upd_a, upd_b = (m.flat_params - init).cpu(), r0 - init.cpu()
+    moved = upd_a.abs().max().item()
+    rel = float((upd_a - upd_b).norm() / upd_b.norm())
+    frac = float(((upd_a - upd_b).abs() > 0.02 * moved).float().mean())
+    print(f"two-rank OCR step vs hand-averaged: relative L2 of the update difference {rel:.4f}, elements off by > 2 % of a step: {frac:.2e}")
+    assert moved > 1e-4 and rel < 0.01 and frac < 1e-3
