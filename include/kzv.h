@@ -164,6 +164,13 @@ int kzv_beam_update(const kzv_beam_state* st, const float* d_top_scores, const i
  * one: keep d_tokens / d_posids / d_valid / d_logits in fixed buffers.  `stream` must not be the default stream.  The
  * active image width / weights must not change between kzv_decode_begin and the last step. */
 int kzv_decode_begin(kzv_model* m, void* stream);
+/* How a step runs (both entry points).  1 (default; KZV_DECODE_ONE_LAUNCH): for the reference decoder's geometry -- hidden 256, 4
+ * heads, FFN 768, <= 128 cached and <= 160 patch keys, 1 / 2 / 4 rows per image -- embeddings, all layers and the LM head's dense
+ * layer are ONE launch (csrc/decode_fused.hip: a workgroup per image owns its beams through every layer), followed by the
+ * vocabulary GEMM.  0, or any other geometry: one launch per operation (~50 per token).  Same results up to fp32 summation order.
+ * -1 returns to the environment's default.  The fragment-ordered weight copies the one-launch step reads (9.6 MB) are refreshed by
+ * the first step after kzv_model_sync_weights. */
+int kzv_set_decode_one_launch(int on);
 int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, const uint8_t* d_valid, int64_t ld_valid,
                           float* d_logits, void* stream);
 

@@ -69,3 +69,24 @@ int kzv_attn_decode(const bf16_t* q, int64_t ldq, const bf16_t* knew, const bf16
 int kzv_kv_rows(const int* src, int* dst, const int64_t* parent, int B, int ld, int len, hipStream_t s);
 int kzv_step_inc(int* d_t, hipStream_t s);
 int kzv_cross_relayout(const bf16_t* src, bf16_t* dst, int images, int keys, int heads, int layers2, hipStream_t s);
+
+// decode_fused.hip: the whole KV-cached decoder step (embeddings .. LM-head dense) of a generation token in one launch
+#define KZV_DECODE_FUSED_MAX_LAYERS 12
+struct KzvDecodeFusedLayer {
+    const bf16_t *wqkv, *wo, *wcq, *wco, *wfc1, *wfc2;          // bf16 copies in MFMA fragment order (kzv_pack_frag)
+    const float *bqkv, *bo, *bcq, *bco, *bfc1, *bfc2;
+    const float *ln1w, *ln1b, *ln2w, *ln2b, *ln3w, *ln3b;
+};
+struct KzvDecodeFused {
+    KzvDecodeFusedLayer layers[KZV_DECODE_FUSED_MAX_LAYERS]; int nlayers;
+    const int64_t* tokens; const int* posids;
+    const float *word, *type0, *postab, *elnw, *elnb;
+    const bf16_t* whd; const float* bhd; float* hd_out;
+    bf16_t* cache; int64_t plane; const bf16_t* ckv; int64_t plane2;
+    const unsigned char* valid; int64_t ldvalid;
+    const int* tptr; int t, T, npa, B, group;
+    int* rows; float eps;
+};
+int kzv_decode_fused_supported(int Hd, int heads, int Fd, int layers, int group, int T, int npa);
+int kzv_decode_fused_launch(const KzvDecodeFused& a, hipStream_t s);
+int kzv_pack_frag(const bf16_t* W, bf16_t* out, int N, int K, hipStream_t s);     // [N, K] row-major -> fragment order

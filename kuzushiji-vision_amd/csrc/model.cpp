@@ -84,6 +84,8 @@ struct kzv_model {
     int* rowtab[2] = {nullptr, nullptr}; int rt_cur = -1;
     // cross-attention K/V re-laid out for the generation steps ([layer][K|V][image][head][key][64]); rebuilt when the encoder ran
     bf16_t* ckv_dec = nullptr; size_t ckv_dec_bytes = 0; bool ckv_dec_ok = false;
+    // the decoder's bf16 weights in MFMA fragment order (decode_fused.hip), refreshed after every weight change
+    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false;
     // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
     int* d_t = nullptr;
     hipGraphExec_t dgraph[3] = {nullptr, nullptr, nullptr};          // one per row table in use: none, rowtab[0], rowtab[1]
@@ -723,6 +725,7 @@ extern "C" int kzv_model_destroy(kzv_model* m) {
         for (int i = 0; i < 2; ++i) if (m->kvc[i]) (void)hipFree(m->kvc[i]);
         for (int i = 0; i < 2; ++i) if (m->rowtab[i]) (void)hipFree(m->rowtab[i]);
         if (m->ckv_dec) (void)hipFree(m->ckv_dec);
+        if (m->dec_pack) (void)hipFree(m->dec_pack);
         for (int i = 0; i < 3; ++i) if (m->dgraph[i]) (void)hipGraphExecDestroy(m->dgraph[i]);
     }
     delete m;
@@ -799,7 +802,7 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
     }
     // a captured decode step holds pointers INTO the workspace and the parameter buffer: none survives a rebind
     for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
-    m->ckv_dec_ok = false;
+    m->ckv_dec_ok = false; m->dec_pack_ok = false;
     m->bound = true; m->have_fwd = false; m->have_enc = false;
     return KZV_OK;
 }
@@ -807,6 +810,7 @@ extern "C" int kzv_model_bind(kzv_model* m, float* d_params, float* d_grads, voi
 extern "C" int kzv_model_sync_weights(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "sync_weights: model not bound");
     KZV_TRY(kzv_cast_weights(m->d_desc, m->ndesc, m->cast_tiles, (hipStream_t)stream));
+    m->dec_pack_ok = false;
     if (m->fp8) {
         if (m->fp8 >= 2 && hipMemsetAsync(m->f8_wnorm, 0, sizeof(float) * m->Le, (hipStream_t)stream) != hipSuccess)
             return kzv_fail(KZV_E_HIP, "sync_weights: memset");
@@ -988,6 +992,76 @@ static int decode_step_body_fused(kzv_model* m, const int64_t* d_tokens, const i
     return kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s);
 }
 
+static int g_decode_one_launch = -1;           // -1: KZV_DECODE_ONE_LAUNCH (default 1)
+static int decode_one_launch_mode() {
+    if (g_decode_one_launch < 0) { const char* e = getenv("KZV_DECODE_ONE_LAUNCH"); g_decode_one_launch = e ? (atoi(e) != 0) : 1; }
+    return g_decode_one_launch;
+}
+extern "C" int kzv_set_decode_one_launch(int on) {
+    if (on < -1 || on > 1) return kzv_fail(KZV_E_ARG, "set_decode_one_launch: -1 (environment default), 0 or 1");
+    g_decode_one_launch = on;
+    return KZV_OK;
+}
+static bool decode_one_launch(const kzv_model* m) {
+    return decode_one_launch_mode() && m->Be >= 1 && m->B % m->Be == 0 && kzv_decode_fused_supported(m->Hd, m->c.dec_heads, m->Fd, m->Ld, m->B / m->Be, m->T, m->npa);
+}
+
+// fragment-ordered copies of the decoder's weights for the one-launch step (9.6 MB; a plain launch, outside any capture)
+static int ensure_dec_pack(kzv_model* m, hipStream_t s) {
+    if (m->dec_pack_ok || !decode_one_launch(m)) return KZV_OK;
+    const int64_t Hd = m->Hd, Fd = m->Fd, per = 3 * Hd * Hd + 3 * Hd * Hd + 2 * Fd * Hd;
+    if (!m->dec_pack) {
+        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(per * m->Ld + Hd * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
+        for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
+    }
+    for (int i = 0; i < m->Ld; ++i) {
+        bf16_t* o = m->dec_pack + per * i;
+        KZV_TRY(kzv_pack_frag(m->w_dqkv[i].w, o, 3 * (int)Hd, (int)Hd, s)); o += 3 * Hd * Hd;
+        KZV_TRY(kzv_pack_frag(m->w_do[i].w, o, (int)Hd, (int)Hd, s)); o += Hd * Hd;
+        KZV_TRY(kzv_pack_frag(m->w_dcq[i].w, o, (int)Hd, (int)Hd, s)); o += Hd * Hd;
+        KZV_TRY(kzv_pack_frag(m->w_dco[i].w, o, (int)Hd, (int)Hd, s)); o += Hd * Hd;
+        KZV_TRY(kzv_pack_frag(m->w_dfc1[i].w, o, (int)Fd, (int)Hd, s)); o += Fd * Hd;
+        KZV_TRY(kzv_pack_frag(m->w_dfc2[i].w, o, (int)Hd, (int)Fd, s));
+    }
+    KZV_TRY(kzv_pack_frag(m->w_hd.w, m->dec_pack + per * m->Ld, (int)Hd, (int)Hd, s));
+    m->dec_pack_ok = true;
+    return KZV_OK;
+}
+
+// The whole step up to the LM head's dense layer in ONE launch (decode_fused.hip: a workgroup per image owns its beams through all
+// layers), then the vocabulary GEMM with the head's LayerNorm folded into its A operand as before.
+static int decode_step_body_one_launch(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const int* tptr, const unsigned char* d_valid,
+                                       int64_t ld_valid, float* d_logits, hipStream_t s) {
+    const int B = m->B, Hd = m->Hd, T = m->T;
+    float* P = m->P;
+    KzvDecodeFused a;
+    memset(&a, 0, sizeof(a));
+    if (!m->dec_pack_ok) return kzv_fail(KZV_E_STATE, "decode_step: the fragment-ordered decoder weights are stale");
+    const int64_t HH = (int64_t)Hd * Hd, FH = (int64_t)m->Fd * Hd, per = 6 * HH + 2 * FH;
+    for (int i = 0; i < m->Ld; ++i) {
+        const DecLayerP& d = m->dp[i];
+        const bf16_t* o = m->dec_pack + per * i;
+        a.layers[i] = KzvDecodeFusedLayer{o, o + 3 * HH, o + 4 * HH, o + 5 * HH, o + 6 * HH, o + 6 * HH + FH,
+                                          P + d.qkvb, P + d.ob, P + d.cqb, P + d.cob, P + d.fc1b, P + d.fc2b,
+                                          P + d.ln1w, P + d.ln1b, P + d.ln2w, P + d.ln2b, P + d.ln3w, P + d.ln3b};
+    }
+    a.nlayers = m->Ld; a.tokens = d_tokens; a.posids = d_posids;
+    a.word = P + m->word; a.type0 = P + m->dtype; a.postab = P + m->dpos; a.elnw = P + m->eln_w; a.elnb = P + m->eln_b;
+    a.whd = m->dec_pack + per * m->Ld; a.bhd = P + m->hd_b; a.hd_out = m->hd_gelu;
+    a.cache = m->kvc[m->kv_cur]; a.plane = (int64_t)B * T * Hd;
+    a.ckv = m->ckv_dec; a.plane2 = (int64_t)m->Be * m->npa * Hd;
+    a.valid = d_valid; a.ldvalid = ld_valid; a.tptr = tptr; a.t = t; a.T = T; a.npa = m->npa; a.B = B; a.group = B / m->Be;
+    a.rows = m->rt_cur >= 0 ? m->rowtab[m->rt_cur] : nullptr; a.eps = m->c.ln_eps;
+    KZV_TRY(kzv_decode_fused_launch(a, s));
+    const float eps = m->c.ln_eps;
+    if (m->V % 4 == 0)
+        return gemm_f(nullptr, 0, m->w_word, B, m->V, Hd, m->V, P + m->hbias, d_logits, m->V, KZV_EPI_F32, s, nullptr, 0, m->hd_gelu, P + m->hln_w, P + m->hln_b,
+                      nullptr, nullptr, nullptr, eps);
+    KZV_TRY(gemm_f(nullptr, 0, m->w_word, B, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s, nullptr, 0, m->hd_gelu, P + m->hln_w, P + m->hln_b,
+                   nullptr, nullptr, nullptr, eps));
+    return kzv_copy_logits(m->logits, m->Vp, d_logits, B, m->V, s);
+}
+
 static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_posids, int t, const int* tptr, const unsigned char* d_valid,
                             int64_t ld_valid, float* d_logits, hipStream_t s) {
     const kzv_config& c = m->c;
@@ -996,6 +1070,7 @@ static int decode_step_body(kzv_model* m, const int64_t* d_tokens, const int* d_
     const float eps = c.ln_eps;
     static int fuse_ln = -1;
     if (fuse_ln < 0) { const char* e = getenv("KZV_DECODE_FUSE_LN"); fuse_ln = e ? atoi(e) : 1; }
+    if (decode_one_launch(m)) return decode_step_body_one_launch(m, d_tokens, d_posids, t, tptr, d_valid, ld_valid, d_logits, s);
     if (fuse_ln && Hd == 256 && B <= 4096) return decode_step_body_fused(m, d_tokens, d_posids, t, tptr, d_valid, ld_valid, d_logits, s);
     KzvRowsScope rows_scope;                     // M = B rows: every GEMM of the step takes the few-rows kernel (gemm_rows.hip)
     bf16_t* cache = m->kvc[m->kv_cur];
@@ -1046,6 +1121,7 @@ extern "C" int kzv_decode_step(kzv_model* m, const int64_t* d_tokens, const int*
     KZV_TRY(ensure_kv_cache(m));
     if (t == 0) m->rt_cur = -1;                 // a new generation: no beam has been re-parented yet
     KZV_TRY(ensure_cross_layout(m, (hipStream_t)stream));
+    KZV_TRY(ensure_dec_pack(m, (hipStream_t)stream));
     m->train = false; m->have_fwd = false;      // decoder activations are overwritten: no backward after this
     return decode_step_body(m, d_tokens, d_posids, t, nullptr, d_valid, ld_valid, d_logits, (hipStream_t)stream);
 }
@@ -1054,6 +1130,7 @@ extern "C" int kzv_decode_begin(kzv_model* m, void* stream) {
     if (!m || !m->bound) return kzv_fail(KZV_E_STATE, "decode_begin: model not bound");
     KZV_TRY(ensure_kv_cache(m));
     if (m->have_enc) KZV_TRY(ensure_cross_layout(m, (hipStream_t)stream));
+    KZV_TRY(ensure_dec_pack(m, (hipStream_t)stream));
     m->rt_cur = -1;                              // a new generation: every sequence reads its own cache row
     if (hipMemsetAsync(m->d_t, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode_begin: memset");
     return KZV_OK;
@@ -1065,10 +1142,11 @@ extern "C" int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, cons
     if (!stream) return kzv_fail(KZV_E_ARG, "decode_step_graph: needs a non-default stream (stream capture)");
     KZV_TRY(ensure_kv_cache(m));
     KZV_TRY(ensure_cross_layout(m, (hipStream_t)stream));          // before any capture: a plain launch, once per generation
+    KZV_TRY(ensure_dec_pack(m, (hipStream_t)stream));
     m->train = false; m->have_fwd = false;
     hipStream_t s = (hipStream_t)stream;
     const int g = m->rt_cur + 1;
-    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[0], (const void*)((intptr_t)m->ckv_dec ^ (intptr_t)(m->npa * 4096 + m->Be))};
+    const void* key[6] = {d_tokens, d_posids, d_valid, d_logits, m->kvc[0], (const void*)((intptr_t)m->ckv_dec ^ (intptr_t)(m->npa * 4096 + m->Be) ^ ((intptr_t)decode_one_launch_mode() << 40))};
     bool same = m->dgraph[g] != nullptr && m->dg_ld[g] == ld_valid;
     for (int i = 0; i < 6 && same; ++i) same = m->dg_key[g][i] == key[i];
     if (!same) {                               // (re)capture: the step with its index read from m->d_t, then t += 1

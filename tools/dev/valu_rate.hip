@@ -30,14 +30,30 @@ KERNEL(k_mulhi24, OP8("v_mul_hi_u32_u24"))
 KERNEL(k_xor, OP8("v_xor_b32"))
 KERNEL(k_add, OP8("v_add_u32"))
 KERNEL(k_lshr, OP8("v_lshrrev_b32"))
-KERNEL(k_exp, OP8_1("v_exp_f32"))
 KERNEL(k_mad24, OP8_3("v_mad_u32_u24"))
 KERNEL(k_xad, OP8_3("v_xad_u32"))
 KERNEL(k_alignbit, OP8_3("v_alignbit_b32"))
 KERNEL(k_perm, OP8_3("v_perm_b32"))
 KERNEL(k_lshladd, OP8_3("v_lshl_add_u32"))
 KERNEL(k_bfe, OP8_3("v_bfe_u32"))
-KERNEL(k_fma, OP8_3("v_fma_f32"))
+KERNEL(k_fmaf, OP8_3("v_fma_f32"))
+KERNEL(k_mulf, OP8("v_mul_f32"))
+KERNEL(k_expf, OP8_1("v_exp_f32"))
+KERNEL(k_rcpf, OP8_1("v_rcp_f32"))
+#define KERNEL2(name, body)                                                                         \
+    __global__ void name(unsigned* out, unsigned long long* cyc, int iters) {                      \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                       \
+        f2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, a4 = a0 + 11.f, a5 = a0 + 13.f, a6 = a0 + 17.f, a7 = a0 + 19.f; \
+        f2 m = {1.0001f, 0.9999f};                                                                  \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                        \
+        for (int i = 0; i < iters; ++i) { REP16(body) }                                              \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                        \
+        f2 r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                                \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = __builtin_bit_cast(unsigned, r[0] + r[1]);      \
+        if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;                                     \
+    }
+KERNEL2(k_pkfma, OP8_3("v_pk_fma_f32"))
+KERNEL2(k_pkmul, OP8("v_pk_mul_f32"))
 KERNEL(k_madu16, OP8_3("v_mad_u16"))
 KERNEL(k_pkmul16, OP8("v_pk_mul_lo_u16"))
 KERNEL(k_pkmad16, OP8_3("v_pk_mad_u16"))
@@ -60,6 +76,8 @@ int main() {
         run("v_alignbit", k_alignbit, threads); run("v_perm_b32", k_perm, threads); run("v_lshl_add", k_lshladd, threads);
         run("v_mad_u16", k_madu16, threads); run("v_pk_mul_lo_u16", k_pkmul16, threads); run("v_pk_mad_u16", k_pkmad16, threads);
         run("v_mul_lo_u16", k_mullo16, threads);
+        run("v_fma_f32", k_fmaf, threads); run("v_mul_f32", k_mulf, threads); run("v_exp_f32", k_expf, threads); run("v_rcp_f32", k_rcpf, threads);
+        run("v_pk_fma_f32", k_pkfma, threads); run("v_pk_mul_f32", k_pkmul, threads);
     }
     return 0;
 }
