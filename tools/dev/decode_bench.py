@@ -14,8 +14,11 @@ m.eval()
 for graph in (os.environ.get("DEC_GRAPHS", "0,1").split(",")):
     os.environ["KZV_DECODE_GRAPH"] = graph
     for beams in [int(b) for b in os.environ.get("DEC_BEAMS", "1,4").split(",")]:
-        for rep in range(2):
+        ts = []
+        for rep in range(int(os.environ.get("DEC_REPS", "6"))):     # the first repetitions capture the graph and ramp the clocks
             torch.cuda.synchronize(); t0 = time.perf_counter()
             out = m.generate(px, max_length=128, num_beams=beams, early_stopping=False)
-            torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"graph={graph} beams={beams}: {dt * 1e3:.1f} ms for {out.shape[1]} tokens x 256 crops ({256 / dt:.0f} img/s)")
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        dt = sorted(ts[2:])[len(ts[2:]) // 2] if len(ts) > 2 else ts[-1]
+        print(f"graph={graph} beams={beams}: {dt * 1e3:.1f} ms for {out.shape[1]} tokens x 256 crops ({256 / dt:.0f} img/s; encoder included; "
+              f"median of the last {max(1, len(ts) - 2)} of {len(ts)} runs)")
