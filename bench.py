@@ -227,7 +227,20 @@ def main():
     # Timed region: HIP events bracket every launch of the reported kernel family only (each bracket costs ~2 us of
     # stream time; gemm_tn / attention are measured in one extra, untimed step below).
     events = not os.environ.get("KZV_BENCH_NO_EVENTS")     # dev knob: step time without any per-launch events
-    stride = int(os.environ.get("KZV_BENCH_EVENT_STRIDE", "4"))
+    stride = int(os.environ.get("KZV_BENCH_EVENT_STRIDE", "0"))
+    if events and stride <= 0:
+        # every s-th launch is bracketed; s must be coprime with the family's launches per step, or the sample only ever sees the
+        # same residue class of positions in the step (142 launches at s = 4: the even ones only -- it read 7 % low).  One untimed
+        # step counts the launches (a sampling period no launch reaches: nothing is bracketed).
+        L.check(lib.kzv_prof_select(1 << 0), "prof_select")
+        L.check(lib.kzv_prof_sample(1 << 30), "prof_sample")
+        L.check(lib.kzv_prof_enable(1, 16), "prof_enable")
+        stepper.step(batch, args.warmup)
+        barrier()
+        L.check(lib.kzv_prof_enable(0, 0), "prof_disable")
+        per_step = int(lib.kzv_prof_seen(0))
+        import math
+        stride = next((c for c in (4, 5, 3, 7, 9, 11) if math.gcd(c, max(per_step, 1)) == 1), 1)
     if events:
         L.check(lib.kzv_prof_select(1 << 0), "prof_select")
         L.check(lib.kzv_prof_sample(stride), "prof_sample")

@@ -171,6 +171,11 @@ int kzv_decode_begin(kzv_model* m, void* stream);
  * -1 returns to the environment's default.  The fragment-ordered weight copies the one-launch step reads (9.6 MB) are refreshed by
  * the first step after kzv_model_sync_weights. */
 int kzv_set_decode_one_launch(int on);
+/* Training / evaluation forward: the linear chains of a decoder layer -- [output projection + dropout + residual -> LayerNorm ->
+ * cross query] and [output projection -> LayerNorm -> fc1 + GELU -> fc2 -> LayerNorm -> the next layer's QKV] -- as TWO launches
+ * per layer (csrc/decoder_chain.hip; hidden 256, 4 heads, FFN 768) instead of nine.  1 (default; KZV_DEC_CHAIN), 0: one launch per
+ * operation, -1: the environment's default.  Same tensors, same rounding points, same dropout bits. */
+int kzv_set_dec_chain(int on);
 int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, const uint8_t* d_valid, int64_t ld_valid,
                           float* d_logits, void* stream);
 

@@ -1,0 +1,332 @@
+// The linear chains of a RoBERTa decoder layer in the TRAINING forward (HF modeling_roberta.py:421-464 under
+// src/models/trocr_model.py:258-297), two launches per layer instead of nine:
+//   A (between the two attentions):  s1 = drop(ctx Wo^T + b) + x;  x1 = LN1(s1);  cq = x1 Wcq^T + b
+//   B (after the cross-attention):   s2 = drop(cctx Wco^T + b) + x1;  x2 = LN2(s2);  act = gelu(x2 Wfc1^T + b);
+//                                    s3 = drop(act Wfc2^T + b) + x2;  x3 = LN3(s3);  [qkv of the NEXT layer = x3 Wqkv^T + b]
+// At the decoder's size (hidden 256, FFN 768, ~15k rows) every one of these is a 15 - 21 us launch for 2 GFLOP: 240 tiles of
+// 128 x 128 leave the chip under one wave per SIMD and the chain is launch- and latency-bound.  The chains are ROW-LOCAL, so one
+// workgroup takes 64 rows through a whole chain: the activations stay in LDS (bf16 A operands, fp32 pre-LayerNorm sums), the
+// weights arrive in MFMA fragment order (decode_fused.hip's pack: a wave-instruction = one contiguous KiB) as one stream per wave
+// with a window of 16 fragments in flight across the GEMM boundaries, and every tensor the backward reads is written on the way
+// (same tensors, same rounding points as the launch-per-operation path: bf16 GEMM operands, fp32 sums / statistics / residuals;
+// the dropout bits of the two residual epilogues are the engine's own -- key, element index m * 256 + n -- so the backward's
+// regenerated masks match).  Each weight fragment feeds four MFMAs (the four 16-row tiles).
+#include "kzv_common.h"
+#include "../../include/kzv.h"
+#include "kzv_host.h"
+#include "kzv_kernels.h"
+
+namespace {
+
+constexpr int HD = 256, FD = 768, RM = 64, RT = RM / 16;
+constexpr int LDH = HD + 8;          // bf16 rows, 256 wide
+constexpr int LDW = FD + 8;          // bf16 rows, 768 wide
+constexpr int LDS_ = HD + 4;         // fp32 rows of a pre-LayerNorm sum
+constexpr int WIN = 16;
+constexpr int LDS_A1 = RM * LDH * 2;                                   // bytes of the 256-wide operand tile
+constexpr int LDS_A = LDS_A1 + RM * LDS_ * 4, LDS_B = LDS_A1 + RM * LDW * 2;
+
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// LDS hand-offs only: global loads stay in flight (see decode_fused.hip)
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CB, int KS>
+__device__ __forceinline__ const char* wave_frags(const bf16_t* Wp, int w) { return (const char*)(Wp + (int64_t)w * KS * 512); }
+template <int CB, int KS>
+__device__ __forceinline__ bf16x8 ld_frag(const char* wb, unsigned wo, int i) {       // fragment i = (k-step i / CB, column block w + 8 (i % CB))
+    const int ks = i / CB, c = i % CB;
+    return *(const bf16x8*)(wb + ((int64_t)(8 * c) * KS + ks) * 1024 + wo);
+}
+template <int CB, int KS>
+__device__ __forceinline__ void fill_window(bf16x8 (&R)[WIN], const char* wb, int lane) {
+    const unsigned wo = (unsigned)lane * 16u;
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) R[i] = ld_frag<CB, KS>(wb, wo, i);
+}
+// acc[c][rt][r] = sum_k W[n][k] * a[m][k],  m = 16 rt + (lane & 15),  n = (w + 8 c) * 16 + 4 (lane >> 4) + r
+template <int CB, int KS, int NCB, int NKS>
+__device__ __forceinline__ void chain_gemm(bf16x8 (&R)[WIN], const char* wb, const char* next, const bf16_t* a_lds, int lda, int lane, f32x4 (&acc)[CB][RT]) {
+    constexpr int F = CB * KS;
+    static_assert(F % WIN == 0 && NCB * NKS >= WIN, "chain_gemm: window");
+    const int l15 = lane & 15, g = lane >> 4;
+    const unsigned wo = (unsigned)lane * 16u;
+    const bf16_t* ap = a_lds + l15 * lda + g * 8;
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[RT];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        const int ks = i / CB, c = i % CB;
+        if (c == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) fa[rt] = *(const bf16x8*)(ap + rt * 16 * lda + ks * 32);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R[i % WIN], fa[rt], acc[c][rt], 0, 0, 0);
+        if (i + WIN < F) R[i % WIN] = ld_frag<CB, KS>(wb, wo, i + WIN);
+        else if (next) R[i % WIN] = ld_frag<NCB, NKS>(next, wo, i + WIN - F);
+    }
+}
+
+struct Drop { unsigned thr16; float inv_keep; unsigned key; };
+
+// 64 rows x 256 bf16 columns, global -> LDS (rows past M read as zeros)
+__device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, bf16_t* dst, int m0, int M, int tid) {
+#pragma unroll
+    for (int q = 0; q < RM * 32 / 512; ++q) {
+        const int idx = tid + q * 512, row = idx >> 5, ch = idx & 31;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m0 + row < M) v = *(const uint4*)(src + (int64_t)(m0 + row) * HD + ch * 8);
+        *(uint4*)(dst + row * LDH + ch * 8) = v;
+    }
+}
+
+// "dropout(linear) + residual" epilogue of a 256-wide GEMM: s = drop(acc + bias) + resid -> the LDS sum tile.  (Nothing goes to
+// global memory from the MFMA layout -- a lane holds 4 columns of 16 different rows there, i.e. 32- / 64-byte pieces of 16 rows per
+// store instruction, which is what made the first version of these kernels 2.7x slower than its byte count: every tensor leaves
+// through an LDS tile as whole rows.)
+__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const float* __restrict__ resid, const Drop& d,
+                                               float* s_lds, int m0, int M, int w, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = (w + 8 * c) * 16 + 4 * g;
+        const float4 bb = *(const float4*)(bias + n0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = rt * 16 + l15, m = m0 + row;
+            if (m < M) {
+                float v[4] = {acc[c][rt][0] + bb.x, acc[c][rt][1] + bb.y, acc[c][rt][2] + bb.z, acc[c][rt][3] + bb.w};
+                if (d.thr16) {
+                    const unsigned e = (unsigned)m * (unsigned)HD + (unsigned)n0;
+                    const unsigned b0 = drop_bits(d.key, e >> 1), b1 = drop_bits(d.key, (e >> 1) + 1);
+                    v[0] *= drop_keep(b0, 0, d.thr16, d.inv_keep); v[1] *= drop_keep(b0, 1, d.thr16, d.inv_keep);
+                    v[2] *= drop_keep(b1, 0, d.thr16, d.inv_keep); v[3] *= drop_keep(b1, 1, d.thr16, d.inv_keep);
+                }
+                const float4 x4 = *(const float4*)(resid + (int64_t)m * HD + n0);
+                *(float4*)(s_lds + row * LDS_ + n0) = make_float4(v[0] + x4.x, v[1] + x4.y, v[2] + x4.z, v[3] + x4.w);
+            }
+        }
+    }
+}
+// LayerNorm of the 64 sum rows (wave w: rows 8 w .. 8 w + 7; a row = one KiB per store), the arithmetic of ln_fwd_kernel: the sum s,
+// x (fp32) and xh (bf16) to global, xh also to the LDS operand tile, (mean, rstd) to stats
+__device__ __forceinline__ void ln_rows(const float* s_lds, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ s_out,
+                                        float* __restrict__ x_out, bf16_t* __restrict__ xh_out, float* __restrict__ stats, bf16_t* a_lds, int m0, int M, int w, int lane) {
+    const float4 gm = *(const float4*)(gamma + lane * 4), bt = *(const float4*)(beta + lane * 4);
+#pragma unroll
+    for (int q = 0; q < RM / 8; ++q) {
+        const int row = w * (RM / 8) + q, m = m0 + row;
+        if (m >= M) {                                 // wave-uniform
+            *(uint2*)(a_lds + row * LDH + lane * 4) = make_uint2(0, 0);
+            continue;
+        }
+        const float4 v = *(const float4*)(s_lds + row * LDS_ + lane * 4);
+        *(float4*)(s_out + (int64_t)m * HD + lane * 4) = v;
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) / (float)HD;
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) / (float)HD + eps);
+        if (lane == 0) { stats[2 * (int64_t)m] = mean; stats[2 * (int64_t)m + 1] = rstd; }
+        const float o0 = a * rstd * gm.x + bt.x, o1 = b * rstd * gm.y + bt.y, o2 = c * rstd * gm.z + bt.z, o3 = d * rstd * gm.w + bt.w;
+        const uint2 h = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+        *(float4*)(x_out + (int64_t)m * HD + lane * 4) = make_float4(o0, o1, o2, o3);
+        *(uint2*)(xh_out + (int64_t)m * HD + lane * 4) = h;
+        *(uint2*)(a_lds + row * LDH + lane * 4) = h;
+    }
+}
+// bf16 output of a GEMM with CB column blocks per wave into an LDS tile: t[row][n] = acc + bias
+template <int CB>
+__device__ __forceinline__ void bf16_to_lds(const f32x4 (&acc)[CB][RT], const float* __restrict__ bias, bf16_t* t, int ldt, int w, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int n0 = (w + 8 * c) * 16 + 4 * g;
+        const float4 bb = *(const float4*)(bias + n0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            *(uint2*)(t + (rt * 16 + l15) * ldt + n0) = make_uint2(pack_bf2(acc[c][rt][0] + bb.x, acc[c][rt][1] + bb.y), pack_bf2(acc[c][rt][2] + bb.z, acc[c][rt][3] + bb.w));
+    }
+}
+// an LDS tile of 64 rows x (16 NCH)-byte... NCH 16-byte pieces per row -> global rows of ldo elements (whole rows, 16 bytes per lane)
+template <int NCH>
+__device__ __forceinline__ void rows_out(const bf16_t* t, int ldt, bf16_t* __restrict__ out, int64_t ldo, int m0, int M, int tid) {
+#pragma unroll
+    for (int q = 0; q < RM * NCH / 512; ++q) {
+        const int idx = tid + q * 512, row = idx / NCH, ch = idx - row * NCH;
+        if (m0 + row < M) *(uint4*)(out + (int64_t)(m0 + row) * ldo + ch * 8) = *(const uint4*)(t + row * ldt + ch * 8);
+    }
+}
+
+struct SegA {
+    const bf16_t* ctx; const float* xres; const bf16_t* wo; const float* bo; Drop drop; const float *g1, *b1; const bf16_t* wcq; const float* bcq;
+    float* s1; float* st1; float* x1; bf16_t* x1h; bf16_t* cq; int M; float eps;
+};
+struct SegB {
+    const bf16_t* cctx; const float* x1; const bf16_t* wco; const float* bco; Drop drop3; const float *g2, *b2;
+    const bf16_t* wfc1; const float* bfc1; const bf16_t* wfc2; const float* bfc2; Drop drop4; const float *g3, *b3;
+    const bf16_t* wqkv; const float* bqkv;                       // the next layer's QKV projection, or null
+    float *s2, *st2, *x2; bf16_t* x2h; bf16_t *pre, *act; float *s3, *st3, *x3; bf16_t* x3h; bf16_t* qkv;
+    int M; float eps;
+};
+
+__global__ __launch_bounds__(512) void dec_chain_a_kernel(const SegA p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* a1 = (bf16_t*)smem;                                   // [RM][LDH] bf16 operand tile
+    float* ssum = (float*)(smem + LDS_A1);                        // [RM][LDS_] pre-LayerNorm sums
+    const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * RM;
+    bf16x8 R[WIN];
+    fill_window<2, 8>(R, wave_frags<2, 8>(p.wo, w), opaque(lane0));
+    load_rows(p.ctx, a1, m0, p.M, opaque(tid));
+    wg_barrier();
+    {
+        const int lane = opaque(lane0);
+        f32x4 acc[2][RT];
+        chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wo, w), wave_frags<2, 8>(p.wcq, w), a1, LDH, lane, acc);
+        resid_epilogue(acc, p.bo, p.xres, p.drop, ssum, m0, p.M, w, lane);
+    }
+    wg_barrier();                // every wave has read the ctx tile and written its part of the sum tile
+    ln_rows(ssum, p.g1, p.b1, p.eps, p.s1, p.x1, p.x1h, p.st1, a1, m0, p.M, w, opaque(lane0));
+    wg_barrier();                // the sum tile is dead: it stages the cross query
+    {
+        const int lane = opaque(lane0);
+        f32x4 acc[2][RT];
+        chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wcq, w), nullptr, a1, LDH, lane, acc);
+        bf16_to_lds<2>(acc, p.bcq, (bf16_t*)ssum, LDH, w, lane);
+    }
+    wg_barrier();
+    rows_out<32>((const bf16_t*)ssum, LDH, p.cq, HD, m0, p.M, opaque(tid));
+}
+
+__global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* a1 = (bf16_t*)smem;                                   // [RM][LDH] bf16 operand tile
+    bf16_t* a2 = (bf16_t*)(smem + LDS_A1);                        // [RM][LDW] the FFN activation; the sum tiles alias it
+    float* ssum = (float*)a2;
+    static_assert(RM * LDS_ * 4 <= RM * LDW * 2, "the sum tile must fit the activation tile");
+    const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * RM;
+    bf16x8 R[WIN];
+    fill_window<2, 8>(R, wave_frags<2, 8>(p.wco, w), opaque(lane0));
+    load_rows(p.cctx, a1, m0, p.M, opaque(tid));
+    wg_barrier();
+    {   // s2 = drop(cctx Wco^T + b) + x1
+        const int lane = opaque(lane0);
+        f32x4 acc[2][RT];
+        chain_gemm<2, 8, 6, 8>(R, wave_frags<2, 8>(p.wco, w), wave_frags<6, 8>(p.wfc1, w), a1, LDH, lane, acc);
+        resid_epilogue(acc, p.bco, p.x1, p.drop3, ssum, m0, p.M, w, lane);
+    }
+    wg_barrier();
+    ln_rows(ssum, p.g2, p.b2, p.eps, p.s2, p.x2, p.x2h, p.st2, a1, m0, p.M, w, opaque(lane0));
+    wg_barrier();                // the sum tile is dead from here: the activation tile may be written
+    {   // act = gelu(x2 Wfc1^T + b) -> the activation tile; the derivative (saved for the backward, KZV_EPI_GELU) leaves in three
+        // passes of 256 columns through the operand tile, which the MFMAs no longer read
+        const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
+        f32x4 acc[6][RT];
+        chain_gemm<6, 8, 2, 24>(R, wave_frags<6, 8>(p.wfc1, w), wave_frags<2, 24>(p.wfc2, w), a1, LDH, lane, acc);
+        wg_barrier();            // every wave has read x2h
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * pass + cc;
+                const int n0 = (w + 8 * c) * 16 + 4 * g;
+                const float4 bb = *(const float4*)(p.bfc1 + n0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int row = rt * 16 + l15;
+                    float y[4], d[4];
+                    gelu_erf_both(acc[c][rt][0] + bb.x, &y[0], &d[0]); gelu_erf_both(acc[c][rt][1] + bb.y, &y[1], &d[1]);
+                    gelu_erf_both(acc[c][rt][2] + bb.z, &y[2], &d[2]); gelu_erf_both(acc[c][rt][3] + bb.w, &y[3], &d[3]);
+                    *(uint2*)(a2 + row * LDW + n0) = make_uint2(pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
+                    *(uint2*)(a1 + row * LDH + n0 - 256 * pass) = make_uint2(pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3]));
+                }
+            }
+            wg_barrier();
+            rows_out<32>(a1, LDH, p.pre + 256 * pass, FD, m0, p.M, opaque(tid));
+            wg_barrier();
+        }
+    }
+    rows_out<96>(a2, LDW, p.act, FD, m0, p.M, opaque(tid));       // (the last barrier above also covers the activation tile)
+    f32x4 acc3[2][RT];
+    {   // s3 = drop(act Wfc2^T + b) + x2
+        const int lane = opaque(lane0);
+        if (p.wqkv) chain_gemm<2, 24, 6, 8>(R, wave_frags<2, 24>(p.wfc2, w), wave_frags<6, 8>(p.wqkv, w), a2, LDW, lane, acc3);
+        else chain_gemm<2, 24, 6, 8>(R, wave_frags<2, 24>(p.wfc2, w), nullptr, a2, LDW, lane, acc3);
+    }
+    wg_barrier();                // every wave has read the activation tile: the sum tile (same memory) may be written
+    resid_epilogue(acc3, p.bfc2, p.x2, p.drop4, ssum, m0, p.M, w, opaque(lane0));
+    wg_barrier();
+    ln_rows(ssum, p.g3, p.b3, p.eps, p.s3, p.x3, p.x3h, p.st3, a1, m0, p.M, w, opaque(lane0));
+    if (!p.wqkv) return;
+    wg_barrier();
+    {   // the next layer's q | k | v = x3 Wqkv^T + b, staged through the (dead) activation tile
+        const int lane = opaque(lane0);
+        f32x4 acc[6][RT];
+        chain_gemm<6, 8, 2, 8>(R, wave_frags<6, 8>(p.wqkv, w), nullptr, a1, LDH, lane, acc);
+        bf16_to_lds<6>(acc, p.bqkv, a2, LDW, w, lane);
+    }
+    wg_barrier();
+    rows_out<96>(a2, LDW, p.qkv, 3 * HD, m0, p.M, opaque(tid));
+}
+
+// every decoder weight of the model -> fragment order, one launch
+struct PackDesc { const uint4* src; uint4* dst; int N, K, t0; };
+struct PackTable { PackDesc d[6 * KZV_DECODE_FUSED_MAX_LAYERS + 1]; int n; };
+__global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    int k = 0;
+    while (k + 1 < tab.n && t >= tab.d[k + 1].t0) ++k;
+    const PackDesc& d = tab.d[k];
+    const int u = t - d.t0, lane = u & 63, f = u >> 6, KS = d.K / 32;
+    const int nb = f / KS, ks = f - nb * KS;
+    d.dst[u] = d.src[((int64_t)(nb * 16 + (lane & 15)) * d.K + ks * 32 + (lane >> 4) * 8) / 8];
+}
+
+}  // namespace
+
+int kzv_dec_chain_supported(int Hd, int Fd) { return Hd == HD && Fd == FD; }
+
+int kzv_dec_chain_a(const KzvDecChainA& a, hipStream_t s) {
+    if (a.M < 1) return kzv_fail(KZV_E_ARG, "dec_chain_a: rows");
+    SegA p;
+    p.ctx = a.ctx; p.xres = a.xres; p.wo = a.wo; p.bo = a.bo; p.g1 = a.g1; p.b1 = a.b1; p.wcq = a.wcq; p.bcq = a.bcq;
+    p.s1 = a.s1; p.st1 = a.st1; p.x1 = a.x1; p.x1h = a.x1h; p.cq = a.cq; p.M = a.M; p.eps = a.eps;
+    p.drop.key = a.drop_key; kzv_drop_params(a.drop_p, &p.drop.thr16, &p.drop.inv_keep);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)dec_chain_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_A); attr_done = true; }
+    hipLaunchKernelGGL(dec_chain_a_kernel, dim3((a.M + RM - 1) / RM), dim3(512), LDS_A, s, p);
+    return kzv_check_launch("dec_chain_a");
+}
+
+int kzv_dec_chain_b(const KzvDecChainB& a, hipStream_t s) {
+    if (a.M < 1) return kzv_fail(KZV_E_ARG, "dec_chain_b: rows");
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)dec_chain_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr_done = true; }
+    SegB p;
+    p.cctx = a.cctx; p.x1 = a.x1; p.wco = a.wco; p.bco = a.bco; p.g2 = a.g2; p.b2 = a.b2; p.wfc1 = a.wfc1; p.bfc1 = a.bfc1; p.wfc2 = a.wfc2; p.bfc2 = a.bfc2;
+    p.g3 = a.g3; p.b3 = a.b3; p.wqkv = a.wqkv; p.bqkv = a.bqkv;
+    p.s2 = a.s2; p.st2 = a.st2; p.x2 = a.x2; p.x2h = a.x2h; p.pre = a.pre; p.act = a.act; p.s3 = a.s3; p.st3 = a.st3; p.x3 = a.x3; p.x3h = a.x3h; p.qkv = a.qkv;
+    p.M = a.M; p.eps = a.eps;
+    p.drop3.key = a.drop3_key; kzv_drop_params(a.drop_p, &p.drop3.thr16, &p.drop3.inv_keep);
+    p.drop4.key = a.drop4_key; kzv_drop_params(a.drop_p, &p.drop4.thr16, &p.drop4.inv_keep);
+    hipLaunchKernelGGL(dec_chain_b_kernel, dim3((a.M + RM - 1) / RM), dim3(512), LDS_B, s, p);
+    return kzv_check_launch("dec_chain_b");
+}
+
+int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s) {
+    if (n < 1 || n > 6 * KZV_DECODE_FUSED_MAX_LAYERS + 1) return kzv_fail(KZV_E_ARG, "pack_frag_multi: 1..%d matrices", 6 * KZV_DECODE_FUSED_MAX_LAYERS + 1);
+    PackTable tab;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (jobs[i].N % 16 || jobs[i].K % 32) return kzv_fail(KZV_E_ARG, "pack_frag_multi: N %% 16, K %% 32");
+        tab.d[i] = PackDesc{(const uint4*)jobs[i].src, (uint4*)jobs[i].dst, jobs[i].N, jobs[i].K, total};
+        total += jobs[i].N * jobs[i].K / 8;
+    }
+    tab.n = n;
+    hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tab, total);
+    return kzv_check_launch("pack_frag_multi");
+}

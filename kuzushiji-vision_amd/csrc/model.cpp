@@ -328,6 +328,15 @@ enum { SITE_ENC_EMB = KZV_SITE_ENC_EMB, SITE_ENC_L = KZV_SITE_ENC_LAYER(0, 0), S
 inline uint32_t key(const kzv_model* m, uint32_t site) { return kzv_drop_key(m->seed, site); }
 inline float dp(const kzv_model* m, float p) { return m->train ? p : 0.f; }
 
+// decoder_chain.hip: the linear chains of a decoder layer as two launches (KZV_DEC_CHAIN, kzv_set_dec_chain; default on)
+int g_dec_chain = -1;
+int dec_chain_mode() {
+    if (g_dec_chain < 0) { const char* e = getenv("KZV_DEC_CHAIN"); g_dec_chain = e ? (atoi(e) != 0) : 1; }
+    return g_dec_chain;
+}
+bool dec_pack_wanted(const kzv_model* m);
+int ensure_dec_pack(kzv_model* m, hipStream_t s);
+
 #define KZV_TRY(expr) do { int rc__ = (expr); if (rc__ != KZV_OK) return rc__; } while (0)
 
 int gemm(const bf16_t* A, int64_t lda, const W16& w, bool transposed, int M, int N, int K, int n_valid, const float* bias,
@@ -488,26 +497,47 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
                           dp(m, c.dec_hidden_dropout), key(m, SITE_DEC_EMB), s));
     // ---- decoder layers (post-LN; HF modeling_roberta.py:421-464) -------------------------------------------
     const float* x = m->xd0; const bf16_t* xh = m->xd0h;
+    // the linear chains between the attentions as two launches per layer (decoder_chain.hip) where the geometry is the reference's
+    const bool chain = dec_chain_mode() && dec_pack_wanted(m) && kzv_dec_chain_supported(Hd, Fd);
+    if (chain) KZV_TRY(ensure_dec_pack(m, s));
+    const int64_t HH = (int64_t)Hd * Hd, FH = (int64_t)Fd * Hd, per = 6 * HH + 2 * FH;
     for (int i = 0; i < m->Ld; ++i) {
         DecAct& a = m->da[i];
         const DecLayerP& d = m->dp[i];
         const uint32_t site = SITE_DEC_L + 8 * i;
-        KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, Md, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
+        if (!chain || i == 0) KZV_TRY(gemm(xh, Hd, m->w_dqkv[i], false, Md, 3 * Hd, Hd, 3 * Hd, P + d.qkvb, a.qkv, 3 * Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, false, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, nullptr, nullptr, nullptr, nullptr,
                      c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
-        KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, Md, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0,
-                     dp(m, c.dec_hidden_dropout), key(m, site + 1)));
-        KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, Md, Hd, eps, 1, 0, 0.f, 0, s));
-        KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, Md, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
+        if (chain) {
+            const bf16_t* wp = m->dec_pack + per * i;
+            KzvDecChainA ca{a.ctx, x, wp + 3 * HH, P + d.ob, dp(m, c.dec_hidden_dropout), key(m, site + 1), P + d.ln1w, P + d.ln1b, wp + 4 * HH, P + d.cqb,
+                            a.s1, a.st1, a.x1, a.x1h, a.cq, Md, eps};
+            KZV_TRY(kzv_dec_chain_a(ca, s));
+        } else {
+            KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, Md, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0,
+                         dp(m, c.dec_hidden_dropout), key(m, site + 1)));
+            KZV_TRY(kzv_ln_fwd_ex(a.s1, P + d.ln1w, P + d.ln1b, a.x1h, a.x1, a.st1, Md, Hd, eps, 1, 0, 0.f, 0, s));
+            KZV_TRY(gemm(a.x1h, Hd, m->w_dcq[i], false, Md, Hd, Hd, Hd, P + d.cqb, a.cq, Hd, KZV_EPI_BF16, s));
+        }
         KZV_TRY(attn(m, false, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
                      nullptr, nullptr, nullptr, nullptr, c.dec_heads, T, m->npa, dp(m, c.dec_attn_dropout), key(m, site + 2), s));
-        KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, Md, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0,
-                     dp(m, c.dec_hidden_dropout), key(m, site + 3)));
-        KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, Md, Hd, eps, 1, 0, 0.f, 0, s));
-        KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, Md, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
-        KZV_TRY(gemm(a.act, Fd, m->w_dfc2[i], false, Md, Hd, Fd, Hd, P + d.fc2b, a.s3, Hd, KZV_EPI_RESID, s, a.x2, nullptr, 0,
-                     dp(m, c.dec_hidden_dropout), key(m, site + 4)));
-        KZV_TRY(kzv_ln_fwd_ex(a.s3, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, Md, Hd, eps, 1, 0, 0.f, 0, s));
+        if (chain) {
+            const bf16_t* wp = m->dec_pack + per * i;
+            const bool more = i + 1 < m->Ld;
+            KzvDecChainB cb{a.cctx, a.x1, wp + 5 * HH, P + d.cob, dp(m, c.dec_hidden_dropout), key(m, site + 3), key(m, site + 4), P + d.ln2w, P + d.ln2b,
+                            wp + 6 * HH, P + d.fc1b, wp + 6 * HH + FH, P + d.fc2b, P + d.ln3w, P + d.ln3b,
+                            more ? m->dec_pack + per * (i + 1) : nullptr, more ? P + m->dp[i + 1].qkvb : nullptr,
+                            a.s2, a.st2, a.x2, a.x2h, a.pre, a.act, a.s3, a.st3, a.x3, a.x3h, more ? m->da[i + 1].qkv : nullptr, Md, eps};
+            KZV_TRY(kzv_dec_chain_b(cb, s));
+        } else {
+            KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, Md, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0,
+                         dp(m, c.dec_hidden_dropout), key(m, site + 3)));
+            KZV_TRY(kzv_ln_fwd_ex(a.s2, P + d.ln2w, P + d.ln2b, a.x2h, a.x2, a.st2, Md, Hd, eps, 1, 0, 0.f, 0, s));
+            KZV_TRY(gemm(a.x2h, Hd, m->w_dfc1[i], false, Md, Fd, Hd, Fd, P + d.fc1b, a.act, Fd, KZV_EPI_GELU, s, nullptr, a.pre, Fd));
+            KZV_TRY(gemm(a.act, Fd, m->w_dfc2[i], false, Md, Hd, Fd, Hd, P + d.fc2b, a.s3, Hd, KZV_EPI_RESID, s, a.x2, nullptr, 0,
+                         dp(m, c.dec_hidden_dropout), key(m, site + 4)));
+            KZV_TRY(kzv_ln_fwd_ex(a.s3, P + d.ln3w, P + d.ln3b, a.x3h, a.x3, a.st3, Md, Hd, eps, 1, 0, 0.f, 0, s));
+        }
         x = a.x3; xh = a.x3h;
     }
     // ---- LM head (HF modeling_roberta.py:877-893; decoder.weight tied to word embeddings :684-687) + CE --------
@@ -997,6 +1027,11 @@ static int decode_one_launch_mode() {
     if (g_decode_one_launch < 0) { const char* e = getenv("KZV_DECODE_ONE_LAUNCH"); g_decode_one_launch = e ? (atoi(e) != 0) : 1; }
     return g_decode_one_launch;
 }
+extern "C" int kzv_set_dec_chain(int on) {
+    if (on < -1 || on > 1) return kzv_fail(KZV_E_ARG, "set_dec_chain: -1 (environment default), 0 or 1");
+    g_dec_chain = on;
+    return KZV_OK;
+}
 extern "C" int kzv_set_decode_one_launch(int on) {
     if (on < -1 || on > 1) return kzv_fail(KZV_E_ARG, "set_decode_one_launch: -1 (environment default), 0 or 1");
     g_decode_one_launch = on;
@@ -1006,27 +1041,35 @@ static bool decode_one_launch(const kzv_model* m) {
     return decode_one_launch_mode() && m->Be >= 1 && m->B % m->Be == 0 && kzv_decode_fused_supported(m->Hd, m->c.dec_heads, m->Fd, m->Ld, m->B / m->Be, m->T, m->npa);
 }
 
-// fragment-ordered copies of the decoder's weights for the one-launch step (9.6 MB; a plain launch, outside any capture)
-static int ensure_dec_pack(kzv_model* m, hipStream_t s) {
-    if (m->dec_pack_ok || !decode_one_launch(m)) return KZV_OK;
+// fragment-ordered copies of the decoder's weights (9.6 MB) for the one-launch generation step and the training forward's linear
+// chains: ONE table-driven launch after every weight change (outside any capture)
+namespace {
+bool dec_pack_wanted(const kzv_model* m) {
+    return m->Hd == 256 && m->c.dec_heads == 4 && m->Fd == 768 && m->Ld >= 1 && m->Ld <= KZV_DECODE_FUSED_MAX_LAYERS;
+}
+int ensure_dec_pack(kzv_model* m, hipStream_t s) {
+    if (m->dec_pack_ok || !dec_pack_wanted(m)) return KZV_OK;
     const int64_t Hd = m->Hd, Fd = m->Fd, per = 3 * Hd * Hd + 3 * Hd * Hd + 2 * Fd * Hd;
     if (!m->dec_pack) {
         if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(per * m->Ld + Hd * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
         for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
     }
+    std::vector<KzvPackJob> jobs;
     for (int i = 0; i < m->Ld; ++i) {
         bf16_t* o = m->dec_pack + per * i;
-        KZV_TRY(kzv_pack_frag(m->w_dqkv[i].w, o, 3 * (int)Hd, (int)Hd, s)); o += 3 * Hd * Hd;
-        KZV_TRY(kzv_pack_frag(m->w_do[i].w, o, (int)Hd, (int)Hd, s)); o += Hd * Hd;
-        KZV_TRY(kzv_pack_frag(m->w_dcq[i].w, o, (int)Hd, (int)Hd, s)); o += Hd * Hd;
-        KZV_TRY(kzv_pack_frag(m->w_dco[i].w, o, (int)Hd, (int)Hd, s)); o += Hd * Hd;
-        KZV_TRY(kzv_pack_frag(m->w_dfc1[i].w, o, (int)Fd, (int)Hd, s)); o += Fd * Hd;
-        KZV_TRY(kzv_pack_frag(m->w_dfc2[i].w, o, (int)Hd, (int)Fd, s));
+        jobs.push_back({m->w_dqkv[i].w, o, 3 * (int)Hd, (int)Hd}); o += 3 * Hd * Hd;
+        jobs.push_back({m->w_do[i].w, o, (int)Hd, (int)Hd}); o += Hd * Hd;
+        jobs.push_back({m->w_dcq[i].w, o, (int)Hd, (int)Hd}); o += Hd * Hd;
+        jobs.push_back({m->w_dco[i].w, o, (int)Hd, (int)Hd}); o += Hd * Hd;
+        jobs.push_back({m->w_dfc1[i].w, o, (int)Fd, (int)Hd}); o += Fd * Hd;
+        jobs.push_back({m->w_dfc2[i].w, o, (int)Hd, (int)Fd});
     }
-    KZV_TRY(kzv_pack_frag(m->w_hd.w, m->dec_pack + per * m->Ld, (int)Hd, (int)Hd, s));
+    jobs.push_back({m->w_hd.w, m->dec_pack + per * m->Ld, (int)Hd, (int)Hd});
+    KZV_TRY(kzv_pack_frag_multi(jobs.data(), (int)jobs.size(), s));
     m->dec_pack_ok = true;
     return KZV_OK;
 }
+}  // namespace
 
 // The whole step up to the LM head's dense layer in ONE launch (decode_fused.hip: a workgroup per image owns its beams through all
 // layers), then the vocabulary GEMM with the head's LayerNorm folded into its A operand as before.

@@ -1,0 +1,66 @@
+"""The decoder layer's linear chains as two launches (csrc/decoder_chain.hip) against the launch-per-operation forward they replace
+(HF RobertaLayer, modeling_roberta.py:421-464, under src/models/trocr_model.py:258-297): same model, same batch, same dropout seed,
+`kzv_set_dec_chain(0 / 1)` -- loss, logits and EVERY gradient (the backward reads the tensors the chains wrote: sums, LayerNorm
+statistics, bf16 operands, the saved GELU derivative, and regenerates their dropout masks).  The oracle-side parity of the chain
+path is what test_model_gpu.py / test_parity_gpu.py / test_configs_gpu.py assert at the same geometry (the chains are the default)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from kzv import _lib as L
+from kzv.config import small_config, tiny_config
+from kzv.data import build_decoder_dir, synthetic_batch
+from kzv.model import TrOCRModel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _default_mode_afterwards():
+    yield
+    L.load().kzv_set_dec_chain(-1)
+
+
+def _run(cfg, tmp_path, B, Lh, train, seed):
+    lib = L.load()
+    d = build_decoder_dir(str(tmp_path / "dec"), cfg)
+    m = TrOCRModel(cfg.encoder_config_dict(), d, init_seed=seed, load_tokenizer=False)
+    px, lab = synthetic_batch(cfg, B, Lh, seed=seed, min_chars=1, max_chars=Lh - 2)
+    pxt, ids = torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()
+    out = []
+    for mode in (0, 1):
+        L.check(lib.kzv_set_dec_chain(mode), "mode")
+        m.train() if train else m.eval()
+        m.zero_grad()
+        loss, logits = m.forward_loss(pxt, ids, want_logits=True, seed=11)
+        grads = None
+        if train:
+            m.backward()
+            grads = m.flat_grads.clone()
+        torch.cuda.synchronize()
+        out.append((float(loss), logits.clone(), grads))
+    return out
+
+
+@pytest.mark.parametrize("B,Lh,train", [(5, 30, True), (3, 12, True), (7, 23, False)])
+def test_chains_equal_the_launch_per_operation_forward(tmp_path, B, Lh, train):
+    cfg = dataclasses.replace(tiny_config(), dec_hidden=256, dec_heads=4, dec_ffn=768, dec_layers=3)       # dropout 0.1 stays on
+    (l0, z0, g0), (l1, z1, g1) = _run(cfg, tmp_path, B, Lh, train, seed=4 + B)
+    dz = float((z0 - z1).abs().max())
+    print(f"B={B} L={Lh} train={train}: loss {l0:.6f} / {l1:.6f}, largest logit difference {dz:.2e}", end="")
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and dz < 1e-4
+    if train:
+        dg = float((g0 - g1).abs().max()); sc = float(g0.abs().max())
+        print(f", largest gradient difference {dg:.2e} of {sc:.2e}")
+        assert dg < 1e-4 * sc                                   # same arithmetic, same dropout bits: differences are summation order at most
+
+
+def test_chains_at_the_benchmark_decoder_geometry(tmp_path):
+    """12 layers, 15 sequences of up to 127 tokens (rows not a multiple of the 64-row workgroup tile), dropout on."""
+    cfg = small_config()
+    (l0, z0, g0), (l1, z1, g1) = _run(cfg, tmp_path, 15, cfg.max_pos - cfg.pad_id - 1, True, seed=2)
+    dz = float((z0 - z1).abs().max()); dg = float((g0 - g1).abs().max()); sc = float(g0.abs().max())
+    print(f"loss {l0:.6f} / {l1:.6f}, largest logit difference {dz:.2e}, largest gradient difference {dg:.2e} of {sc:.2e}")
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and dz < 1e-4 and dg < 1e-4 * sc
