@@ -8,8 +8,9 @@ all-reduce + clip 1.0 + RAdamScheduleFree + bf16 weight refresh), synthetic 64x6
 
 Prints ONE JSON line (rank 0).  value = line-images/s of the whole job (all ranks), inputs resident in HBM.
 roofline: the bf16 MFMA GEMM family gemm_nt_kernel<*> (every nn.Linear forward and input-gradient), timed live
-with HIP events inside the timed region (kzv_prof_*: every 4th launch is bracketed -- a bracket costs ~2 us of stream
-time, and 4 is co-prime to the launches per step, so every launch site is sampled equally often), priced by its
+with HIP events inside the timed region (kzv_prof_*: every s-th launch is bracketed -- a bracket costs ~2 us of stream
+time; s is the first of 4, 5, 3, 7 co-prime to the family's launches per step, counted in one untimed step, so that every
+launch site is sampled equally often), priced by its
 algorithmic 2*M*N*K FLOPs against the 2.5 PFLOP/s dense bf16 peak of /opt/skills/guides/MI355X_MICROARCH.md.
 cpu_baseline: oracle/trocr_oracle.py (a port, not the reference) timed on this box's host cores, rank 0, N=1.
 """
