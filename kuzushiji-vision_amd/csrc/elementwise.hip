@@ -63,39 +63,69 @@ __global__ void embed_assemble_kernel(const float* __restrict__ pe, const float*
     ((float4*)(x0 + row * He))[c] = make_float4(o0, o1, o2, o3);
 }
 
-// (Round 3 tried to parallelise this pass over the batch -- slices of the batch per thread, strips of positions, 4 - 8 loads in flight,
-// atomics for the sums: 126 - 289 us against 147 us for this form, whose one-writer sums are also bit-reproducible.  Not the loads:
-// the float atomics of many adders on the 768 bias addresses.)
-// thread = (s, 4 columns): loops over the batch; writes dpatch (bf16), dpos (+= sum_b), dcls, patch-bias grad.
-__global__ void embed_assemble_bwd_kernel(const float* __restrict__ dx0, bf16_t* __restrict__ dpatch, float* dcls,
-                                          float* dpos, float* dpbias, int B, int np, int He, unsigned thr16,
-                                          float inv_keep, unsigned key, int gw, int gw_max) {
+// Backward of the embedding assembly in three small launches, every sum in a fixed order (no atomics: bit-reproducible).
+//   1. thread = (token s, 4 columns, batch chunk of EAB_CHUNK samples): masks dx0, writes dpatch (bf16), and its partial sum over the
+//      chunk -> part[chunk][s][He].  (One thread per (s, columns) looping over the WHOLE batch -- the first form -- was 30k threads
+//      with 256 dependent-address loads each: 145 us for 190 MB; slices of the batch with atomic sums were tried at 126 - 289 us: the
+//      float atomics of many adders on the 768 bias addresses.)
+//   2. thread = (s, 4 columns): adds the chunks' partials in order -> dpos (+=), dcls (+=, s = 0), and the token's total -> tok[s][He]
+//   3. thread = 4 columns: patch-bias gradient += sum over the patch tokens of tok, in order
+constexpr int EAB_CHUNK = 32;
+__global__ void embed_assemble_bwd_part_kernel(const float* __restrict__ dx0, bf16_t* __restrict__ dpatch, float* __restrict__ part, int B, int np, int He,
+                                               unsigned thr16, float inv_keep, unsigned key) {
     const int S = np + 1, h4 = He / 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S * h4) return;
-    const int c = t % h4, s = t / h4;
+    const int c = t % h4, s = t / h4, chunk = blockIdx.y;
+    const int b0 = chunk * EAB_CHUNK, b1 = min(B, b0 + EAB_CHUNK);
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int b = 0; b < B; ++b) {
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) {
         const int64_t row = (int64_t)b * S + s;
         float4 d = ((const float4*)(dx0 + row * He))[c];
         if (thr16) {
             const unsigned e = (unsigned)row * (unsigned)He + 4u * c;
-            const unsigned b0 = drop_bits(key, e >> 1), b1 = drop_bits(key, (e >> 1) + 1);
-            d.x *= drop_keep(b0, 0, thr16, inv_keep); d.y *= drop_keep(b0, 1, thr16, inv_keep);
-            d.z *= drop_keep(b1, 0, thr16, inv_keep); d.w *= drop_keep(b1, 1, thr16, inv_keep);
+            const unsigned q0 = drop_bits(key, e >> 1), q1 = drop_bits(key, (e >> 1) + 1);
+            d.x *= drop_keep(q0, 0, thr16, inv_keep); d.y *= drop_keep(q0, 1, thr16, inv_keep);
+            d.z *= drop_keep(q1, 0, thr16, inv_keep); d.w *= drop_keep(q1, 1, thr16, inv_keep);
         }
         a0 += d.x; a1 += d.y; a2 += d.z; a3 += d.w;
         if (s > 0) ((uint2*)(dpatch + ((int64_t)b * np + s - 1) * He))[c] = make_uint2(pack_bf2(d.x, d.y), pack_bf2(d.z, d.w));
     }
+    ((float4*)(part + ((int64_t)chunk * S + s) * He))[c] = make_float4(a0, a1, a2, a3);
+}
+__global__ void embed_assemble_bwd_tok_kernel(const float* __restrict__ part, float* __restrict__ tok, float* dcls, float* dpos, int nchunk, int np, int He,
+                                              int gw, int gw_max) {
+    const int S = np + 1, h4 = He / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * h4) return;
+    const int c = t % h4, s = t / h4;
+    float4 a = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < nchunk; ++k) {
+        const float4 v = ((const float4*)(part + ((int64_t)k * S + s) * He))[c];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    ((float4*)(tok + (int64_t)s * He))[c] = a;
     float* dp = dpos + (int64_t)pos_row(s, gw, gw_max) * He + 4 * c;
-    dp[0] += a0; dp[1] += a1; dp[2] += a2; dp[3] += a3;
+    dp[0] += a.x; dp[1] += a.y; dp[2] += a.z; dp[3] += a.w;
     if (s == 0) {
         float* dc = dcls + 4 * c;
-        dc[0] += a0; dc[1] += a1; dc[2] += a2; dc[3] += a3;
-    } else {
-        float* db = dpbias + 4 * c;
-        atomicAdd(db + 0, a0); atomicAdd(db + 1, a1); atomicAdd(db + 2, a2); atomicAdd(db + 3, a3);
+        dc[0] += a.x; dc[1] += a.y; dc[2] += a.z; dc[3] += a.w;
     }
+}
+__global__ void embed_assemble_bwd_bias_kernel(const float* __restrict__ tok, float* dpbias, int np, int He) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= He / 4) return;
+    float4 a = make_float4(0, 0, 0, 0);
+    for (int s0 = 1; s0 <= np; s0 += 16) {          // 16 loads in flight, added in token order
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ((const float4*)(tok + (int64_t)min(s0 + j, np) * He))[c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (s0 + j <= np) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    float* db = dpbias + 4 * c;
+    db[0] += a.x; db[1] += a.y; db[2] += a.z; db[3] += a.w;
 }
 
 // ------------------------------------------------------------------------------- cast/drop + column sums
@@ -466,9 +496,20 @@ int kzv_embed_assemble(const float* pe, const float* cls, const float* pos, floa
 int kzv_embed_assemble_bwd(const float* dx0, bf16_t* dpatch, float* dcls, float* dpos, float* dpbias, int B, int np, int He,
                            float drop_p, uint32_t key, hipStream_t s, int gw, int gw_max) {
     unsigned thr; float ik; kzv_drop_params(drop_p, &thr, &ik);
-    const int total = (np + 1) * (He / 4);
+    const int S = np + 1, total = S * (He / 4), nchunk = (B + EAB_CHUNK - 1) / EAB_CHUNK;
     if (gw <= 0 || gw_max <= 0) gw = gw_max = 1;
-    hipLaunchKernelGGL(embed_assemble_bwd_kernel, dim3(nblk(total, 64)), dim3(64), 0, s, dx0, dpatch, dcls, dpos, dpbias, B, np, He, thr, ik, key, gw, gw_max);
+    // partial sums [nchunk + 1][S][He] fp32: a process-global scratch grown on demand (calls are stream-ordered)
+    static float* scratch = nullptr; static size_t scratch_floats = 0;
+    const size_t need = (size_t)(nchunk + 1) * S * He;
+    if (need > scratch_floats) {
+        if (scratch) { (void)hipDeviceSynchronize(); (void)hipFree(scratch); scratch = nullptr; scratch_floats = 0; }
+        if (hipMalloc((void**)&scratch, need * sizeof(float)) != hipSuccess) return kzv_fail(KZV_E_HIP, "embed_assemble_bwd: scratch (%zu bytes)", need * sizeof(float));
+        scratch_floats = need;
+    }
+    float* tok = scratch + (size_t)nchunk * S * He;
+    hipLaunchKernelGGL(embed_assemble_bwd_part_kernel, dim3(nblk(total, 64), nchunk), dim3(64), 0, s, dx0, dpatch, scratch, B, np, He, thr, ik, key);
+    hipLaunchKernelGGL(embed_assemble_bwd_tok_kernel, dim3(nblk(total, 64)), dim3(64), 0, s, scratch, tok, dcls, dpos, nchunk, np, He, gw, gw_max);
+    hipLaunchKernelGGL(embed_assemble_bwd_bias_kernel, dim3(nblk(He / 4, 64)), dim3(64), 0, s, tok, dpbias, np, He);
     return kzv_check_launch("embed_assemble_bwd");
 }
 

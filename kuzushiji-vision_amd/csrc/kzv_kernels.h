@@ -16,6 +16,11 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
                   float drop_p, uint32_t drop_key, hipStream_t s, bf16_t* out16 = nullptr, float out_drop_p = 0.f,
                   uint32_t out_drop_key = 0, const KzvLnBwdF8* f8 = nullptr);
 
+// While one of these is alive, kzv_ln_bwd_ex leaves the fold of its gamma / beta partial sums pending (each call gets a partial
+// region of its own); the outermost scope's destructor folds all of them in ONE launch on `stream`.  Without a scope every call
+// folds at once (the per-op C ABI).
+struct KzvLnDeferScope { explicit KzvLnDeferScope(hipStream_t stream); ~KzvLnDeferScope(); hipStream_t s; };
+
 // elementwise.hip
 int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s);
 // gw / gw_max: patches per grid row of this batch / of the position table (width buckets: row of patch p = (p / gw) * gw_max + p % gw)

@@ -1248,9 +1248,12 @@ extern "C" int kzv_backward_segment(kzv_model* m, int seg, void* stream) {
     if (seg < 0 || seg >= m->Le + 2) return kzv_fail(KZV_E_ARG, "backward: bad segment");
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (seg == 0) rc = backward_decoder(m, s);
-    else if (seg <= m->Le) rc = backward_enc_layer(m, m->Le - seg, s);
-    else rc = backward_embed(m, s);
+    {
+        KzvLnDeferScope ln_folds(s);             // the segment's LayerNorm gamma / beta folds: one launch when the scope closes (under
+        if (seg == 0) rc = backward_decoder(m, s);              // kzv_backward: when ITS scope closes, once per backward pass)
+        else if (seg <= m->Le) rc = backward_enc_layer(m, m->Le - seg, s);
+        else rc = backward_embed(m, s);
+    }
     if (rc != KZV_OK) return rc;
     // contract: in `stream` order, this segment's gradient range is final -> the side stream must be joined
     // (kzv_backward, which has no consumer between segments, joins once at the end instead)
@@ -1263,7 +1266,10 @@ extern "C" int kzv_backward(kzv_model* m, void* stream) {
     const int n = kzv_backward_segments(m);
     m->join_each_segment = false;
     int rc = KZV_OK;
-    for (int sgm = 0; sgm < n && rc == KZV_OK; ++sgm) rc = kzv_backward_segment(m, sgm, stream);
+    {
+        KzvLnDeferScope ln_folds((hipStream_t)stream);
+        for (int sgm = 0; sgm < n && rc == KZV_OK; ++sgm) rc = kzv_backward_segment(m, sgm, stream);
+    }
     m->join_each_segment = true;
     if (rc != KZV_OK) (void)join_side(m, (hipStream_t)stream);
     return rc;
