@@ -12,3 +12,7 @@ struct TnParams {
 // gemm_tn256.hip: returns 1 when it took the launch (p.splits / p.chunk are chosen inside), 0 when the shape is left
 // to the 128x128 kernel.
 int kzv_tn256_launch(const TnParams& p, hipStream_t s);
+
+// While one of these is alive, kzv_tn256_launch leaves the fold of its partial tiles pending (each launch gets a workspace region of
+// its own, up to 5); the outermost scope's destructor folds all of them in ONE launch on `stream` (the launches must be on it too).
+struct KzvTnFoldScope { explicit KzvTnFoldScope(hipStream_t stream); ~KzvTnFoldScope(); hipStream_t s; };

@@ -30,6 +30,7 @@
 #include "../../include/kzv.h"
 #include "kzv_host.h"
 #include "gemm_tn.h"
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -282,16 +283,63 @@ __global__ __launch_bounds__(256) void gemm_tn256_fold_kernel(const float* part_
     *o += s;
 }
 
-float* tn_partials(size_t floats) {      // grow-only workspace (calls are stream-ordered; the fold kernel of a launch reads it
-    static float* buf = nullptr;         // before the next launch's partial stores, in the same stream)
-    static size_t cap = 0;
-    if (floats > cap) {
-        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
+// Partial-tile workspace: TN_REGIONS regions of the largest size asked for so far (grow-only; calls are stream-ordered).  Region 0
+// serves a launch whose fold follows at once; regions 1.. the launches of a KzvTnFoldScope (the four weight gradients of an encoder
+// layer), whose folds are ONE launch when the scope closes: a fold is ~5 us of launch latency + ~5 us of data, 49 times per step.
+constexpr int TN_REGIONS = 6;
+float* g_tn_buf = nullptr;
+size_t g_tn_region = 0;                  // floats per region
+float* tn_partials(size_t floats, int region) {
+    if (floats > g_tn_region) {
+        if (g_tn_buf) { (void)hipDeviceSynchronize(); (void)hipFree(g_tn_buf); g_tn_buf = nullptr; g_tn_region = 0; }
         void* q = nullptr;
-        if (hipMalloc(&q, floats * sizeof(float)) != hipSuccess) return nullptr;
-        buf = (float*)q; cap = floats;
+        if (hipMalloc(&q, (size_t)TN_REGIONS * floats * sizeof(float)) != hipSuccess) return nullptr;
+        g_tn_buf = (float*)q; g_tn_region = floats;
     }
-    return buf;
+    return g_tn_buf + (size_t)region * g_tn_region;
+}
+
+struct TnFold { const float* ws; float* OUT; int64_t ldo; int n_store, K, tilesK, per, splits, block0; };
+struct TnFoldTable { TnFold e[TN_REGIONS - 1]; int n; };
+// the folds of a scope in one launch: a block finds its entry by its index (entries hold 64 blocks per output tile)
+__global__ __launch_bounds__(256) void gemm_tn256_fold_multi_kernel(const TnFoldTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.e[k + 1].block0) ++k;
+    const TnFold& e = t.e[k];
+    const int bid = blockIdx.x - e.block0;
+    const int tile = bid >> 6;
+    const int row = (bid & 63) * 4 + (threadIdx.x >> 6), k4 = (threadIdx.x & 63) * 4;
+    const int tnb = tile / e.tilesK, tkb = tile - tnb * e.tilesK;
+    const int gn = tnb * 256 + row, gk = tkb * 256 + k4;
+    if (gn >= e.n_store || gk >= e.K) return;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef KZV_TN_F32_PARTIALS
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2p;
+#pragma unroll 4
+    for (int sp = 0; sp < e.splits; ++sp) {
+        const u32x2p u = __builtin_nontemporal_load((const u32x2p*)((const bf16_t*)(e.ws + ((size_t)sp * e.per + tile) * 65536) + row * 256 + k4));
+        s[0] += bf2f((bf16_t)(u[0] & 0xffffu)); s[1] += bf2f((bf16_t)(u[0] >> 16)); s[2] += bf2f((bf16_t)(u[1] & 0xffffu)); s[3] += bf2f((bf16_t)(u[1] >> 16));
+    }
+#else
+    const float* src = e.ws + ((size_t)tile * 256 + row) * 256 + k4;
+#pragma unroll 4
+    for (int sp = 0; sp < e.splits; ++sp) s += __builtin_nontemporal_load((const f32x4*)(src + (size_t)sp * e.per * 65536));
+#endif
+    f32x4* o = (f32x4*)(e.OUT + (int64_t)gn * e.ldo + gk);
+    *o += s;
+}
+int g_tn_defer = 0;
+std::vector<TnFold> g_tn_pending;
+std::vector<size_t> g_tn_pending_floats;
+int tn_flush(hipStream_t s) {
+    if (g_tn_pending.empty()) return KZV_OK;
+    TnFoldTable t;
+    int blocks = 0;
+    for (size_t i = 0; i < g_tn_pending.size(); ++i) { t.e[i] = g_tn_pending[i]; t.e[i].block0 = blocks; blocks += g_tn_pending[i].per * 64; }
+    t.n = (int)g_tn_pending.size();
+    hipLaunchKernelGGL(gemm_tn256_fold_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    g_tn_pending.clear();
+    return kzv_check_launch("gemm_tn256_fold");
 }
 
 int tn256_min_tiles() {
@@ -331,10 +379,22 @@ int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; }
     if (p.K % 4 || p.ldo % 4 || ((uintptr_t)p.OUT & 15)) return 0;
-    float* ws = tn_partials((size_t)tiles * splits * 65536);
+    const size_t need = (size_t)tiles * splits * 65536;
+    const bool deferred = g_tn_defer > 0;
+    if (deferred && ((int)g_tn_pending.size() == TN_REGIONS - 1 || need > g_tn_region)) {
+        if (tn_flush(s) != KZV_OK) return 0;     // no free region, or the workspace is about to be re-allocated: fold what is pending first
+    }
+    float* ws = tn_partials(need, deferred ? 1 + (int)g_tn_pending.size() : 0);
     if (!ws) return 0;
     hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * splits), dim3(512), LDS_BYTES, s, p, ws);
+    if (deferred) {
+        g_tn_pending.push_back(TnFold{ws, p.OUT, p.ldo, p.n_store, p.K, (p.K + 255) / 256, tiles, splits, 0});
+        return 1;
+    }
     hipLaunchKernelGGL(gemm_tn256_fold_kernel, dim3(tiles * 64), dim3(256), 0, s, ws, p.OUT, p.ldo, p.n_store, p.K,
                        (p.K + 255) / 256, tiles, splits);
     return 1;
 }
+
+KzvTnFoldScope::KzvTnFoldScope(hipStream_t stream) : s(stream) { ++g_tn_defer; }
+KzvTnFoldScope::~KzvTnFoldScope() { if (--g_tn_defer == 0) (void)tn_flush(s); }

@@ -12,6 +12,7 @@
 #include "kzv_kernels.h"
 #include "../../include/kzv.h"
 #include "gemm_nt.h"
+#include "gemm_tn.h"
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -647,6 +648,8 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     float* P = m->P; float* G = m->G;
     EncAct& a = m->ea[i];
     const EncLayerP& e = m->ep[i];
+    // the layer's four weight-gradient GEMMs fold their partial tiles in one launch at the end of the layer (one stream only)
+    struct TnFolds { KzvTnFoldScope* sc; ~TnFolds() { delete sc; } } tn_folds{m->use_side ? nullptr : new KzvTnFoldScope(s)};
     if (m->side_mode == 2) {
         // Overlap mode 2: the four weight-gradient GEMMs (MFMA-bound, 710 us per layer) run on the side stream ONLY while
         // the caller's stream runs an HBM- or issue-bound kernel (LayerNorm backward x2, attention backward: 344 us per
