@@ -10,9 +10,11 @@
  * by the caller (torch tensors in the Python host): parameters, gradients, optimizer state and one workspace
  * sized by kzv_workspace_bytes.  The library itself allocates only small or grow-only scratch on the current device,
  * kept for the life of the process (one device per process): a 4 KiB page of zeros (LDS-DMA loads of out-of-range
- * tile rows are pointed at it), the LayerNorm gamma/beta partial rows (512 KiB), the gemm_tn256 partial-tile
- * workspace (<= 66 MB) and, per model handle, the generation path's KV cache, beam row tables and decode-layout copy of the
- * cross-attention K/V (allocated at the first kzv_decode_step / kzv_decode_begin, freed by kzv_model_destroy).
+ * tile rows are pointed at it), the LayerNorm gamma/beta partial rows (64 regions of 512 KiB: the folds of a backward pass are one
+ * launch), the gemm_tn256 partial-tile workspace (6 regions of <= 66 MB: the folds of an encoder layer's four weight gradients are
+ * one launch), the embedding backward's partial sums (~5 MB at batch 256) and, per model handle, the generation path's KV cache,
+ * beam row tables, decode-layout copy of the cross-attention K/V and the fragment-ordered copy of the decoder weights (9.6 MB;
+ * allocated at the first kzv_decode_step / kzv_decode_begin or training forward that needs them, freed by kzv_model_destroy).
  * Other global state: the last-error string, the profiling slots and the CU reserve.  `stream` is a hipStream_t passed as void*.
  * One model handle per process/GPU; a handle is not re-entrant.
  */
