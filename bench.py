@@ -150,6 +150,13 @@ def cpu_baseline(cfg, label_len, sample_batch, steps, budget_s=30.0):
                       + f" (host has {all_threads}); {dt:.2f} s/step; whole leg {time.perf_counter() - t_begin:.0f} s"}
 
 
+def pick_stride(launches_per_step: int) -> int:
+    """Sampling period of the per-launch events: the first of 4, 5, 3, 7, 9, 11 co-prime to the family's launches per step (every launch
+    site is then bracketed equally often over that many steps); 1 = bracket everything if none is."""
+    import math
+    return next((c for c in (4, 5, 3, 7, 9, 11) if math.gcd(c, max(launches_per_step, 1)) == 1), 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,9 +246,7 @@ def main():
         stepper.step(batch, args.warmup)
         barrier()
         L.check(lib.kzv_prof_enable(0, 0), "prof_disable")
-        per_step = int(lib.kzv_prof_seen(0))
-        import math
-        stride = next((c for c in (4, 5, 3, 7, 9, 11) if math.gcd(c, max(per_step, 1)) == 1), 1)
+        stride = pick_stride(int(lib.kzv_prof_seen(0)))
     if events:
         L.check(lib.kzv_prof_select(1 << 0), "prof_select")
         L.check(lib.kzv_prof_sample(stride), "prof_sample")

@@ -272,3 +272,19 @@ def test_beam_and_greedy_bookkeeping_equal_hf_generate():
             for t, rows in rows_seen:               # cache rows: every row continues from a row of its own batch element
                 assert rows.shape == (B * nb,) and torch.equal(rows // nb, torch.arange(B).repeat_interleave(nb))
     assert n_eos_endings > 10                        # the EOS / finished-hypothesis paths were exercised
+
+
+def test_bench_event_stride_is_coprime_with_the_launch_count():
+    """bench.py brackets every s-th launch of the reported kernel family; s sharing a factor with the launches per step samples one
+    residue class of launch sites only (142 launches at s = 4 read the family 7 % low on the GPU)."""
+    import importlib.util
+    import math
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.pick_stride(177) == 4 and bench.pick_stride(142) == 5 and bench.pick_stride(60) == 7
+    for n in range(1, 400):
+        s_ = bench.pick_stride(n)
+        assert math.gcd(s_, n) == 1 and 1 <= s_ <= 11
+    assert bench.pick_stride(4 * 5 * 3 * 7 * 11) == 1          # nothing co-prime among the candidates: bracket every launch
