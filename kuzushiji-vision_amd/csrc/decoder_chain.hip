@@ -70,6 +70,13 @@ __device__ __forceinline__ void chain_gemm(bf16x8 (&R)[WIN], const char* wb, con
     }
 }
 
+#ifdef KZV_STAMPS      // diagnostic build (tools/dev/stamps_chain.py): the phase timeline of workgroup 0 of the last dec_chain_b launch
+__device__ long long g_chain_stamps[32];
+#define CH_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chain_stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CH_STAMP(k)
+#endif
+
 struct Drop { unsigned thr16; float inv_keep; unsigned key; };
 
 // 64 rows x 256 bf16 columns, global -> LDS (rows past M read as zeros)
@@ -209,9 +216,11 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * RM;
     bf16x8 R[WIN];
+    CH_STAMP(0);
     fill_window<2, 8>(R, wave_frags<2, 8>(p.wco, w), opaque(lane0));
     load_rows(p.cctx, a1, m0, p.M, opaque(tid));
     wg_barrier();
+    CH_STAMP(1);
     {   // s2 = drop(cctx Wco^T + b) + x1
         const int lane = opaque(lane0);
         f32x4 acc[2][RT];
@@ -219,14 +228,17 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
         resid_epilogue(acc, p.bco, p.x1, p.drop3, ssum, m0, p.M, w, lane);
     }
     wg_barrier();
+    CH_STAMP(2);
     ln_rows(ssum, p.g2, p.b2, p.eps, p.s2, p.x2, p.x2h, p.st2, a1, m0, p.M, w, opaque(lane0));
     wg_barrier();                // the sum tile is dead from here: the activation tile may be written
+    CH_STAMP(3);
     {   // act = gelu(x2 Wfc1^T + b) -> the activation tile; the derivative (saved for the backward, KZV_EPI_GELU) leaves in three
         // passes of 256 columns through the operand tile, which the MFMAs no longer read
         const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
         f32x4 acc[6][RT];
         chain_gemm<6, 8, 2, 24>(R, wave_frags<6, 8>(p.wfc1, w), wave_frags<2, 24>(p.wfc2, w), a1, LDH, lane, acc);
         wg_barrier();            // every wave has read x2h
+        CH_STAMP(4);
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
@@ -249,7 +261,9 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
             wg_barrier();
         }
     }
+    CH_STAMP(5);
     rows_out<96>(a2, LDW, p.act, FD, m0, p.M, opaque(tid));       // (the last barrier above also covers the activation tile)
+    CH_STAMP(6);
     f32x4 acc3[2][RT];
     {   // s3 = drop(act Wfc2^T + b) + x2
         const int lane = opaque(lane0);
@@ -257,9 +271,12 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
         else chain_gemm<2, 24, 6, 8>(R, wave_frags<2, 24>(p.wfc2, w), nullptr, a2, LDW, lane, acc3);
     }
     wg_barrier();                // every wave has read the activation tile: the sum tile (same memory) may be written
+    CH_STAMP(7);
     resid_epilogue(acc3, p.bfc2, p.x2, p.drop4, ssum, m0, p.M, w, opaque(lane0));
     wg_barrier();
+    CH_STAMP(8);
     ln_rows(ssum, p.g3, p.b3, p.eps, p.s3, p.x3, p.x3h, p.st3, a1, m0, p.M, w, opaque(lane0));
+    CH_STAMP(9);
     if (!p.wqkv) return;
     wg_barrier();
     {   // the next layer's q | k | v = x3 Wqkv^T + b, staged through the (dead) activation tile
@@ -269,7 +286,9 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
         bf16_to_lds<6>(acc, p.bqkv, a2, LDW, w, lane);
     }
     wg_barrier();
+    CH_STAMP(10);
     rows_out<96>(a2, LDW, p.qkv, 3 * HD, m0, p.M, opaque(tid));
+    CH_STAMP(11);
 }
 
 // every decoder weight of the model -> fragment order, one launch
@@ -287,6 +306,12 @@ __global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
 }
 
 }  // namespace
+
+#ifdef KZV_STAMPS
+extern "C" int kzv_debug_chain_stamps(long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chain_stamps), sizeof(long long) * (n < 32 ? n : 32)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int kzv_dec_chain_supported(int Hd, int Fd) { return Hd == HD && Fd == FD; }
 
