@@ -126,12 +126,14 @@ def cpu_baseline(cfg, label_len, sample_batch, steps, budget_s=30.0):
             out[n] = one_step(w)
         return out
     w = make(sample_batch)
+    torch.set_num_threads(min(16, all_threads))               # (at all 128 host threads the warm-up alone took 12 s and pushed the leg to batch 8)
     one_step(w)                                               # warm-up (allocations, first touch: several times a steady step)
     sweep = sweep_threads(w)
     # the stated fallback: steady steps of batch 16 that would not leave room for two timed ones inside the budget -> batch 8
     if sample_batch > 8 and (time.perf_counter() - t_begin) + 2 * min(sweep.values()) > budget_s:
         sample_batch = 8
         w = make(sample_batch)
+        torch.set_num_threads(min(16, all_threads))
         one_step(w)
         sweep = sweep_threads(w)
     best = min(sweep, key=sweep.get)
