@@ -240,6 +240,12 @@ int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream);
  * never; KZV_ROWS_MAX_M), which takes the few-rows kernel the generation step (kzv_decode_step*) uses internally for its
  * M = batch GEMMs (one wave per 16x64 tile).  The per-op tests raise the threshold to check that kernel through this entry. */
 int kzv_set_rows_max_m(int n);
+/* K-loop schedule of the persistent 256x256 kernel behind kzv_gemm_nt (large shapes, one-store epilogues): 0 = eight-phase
+ * ping-pong (gemm_nt256p.hip), 1 = free-running, two barriers per K-tile (gemm_nt256f.hip).  Same results bit for bit (same
+ * per-accumulator summation order).  Default: KZV_NT_FREE (environment) or the library's choice; n < 0 restores the default. */
+int kzv_set_nt_schedule(int n);
+/* The same choice for the 256x256 weight-gradient kernel behind kzv_gemm_tn (gemm_tn256.hip; KZV_TN_FREE). */
+int kzv_set_tn_schedule(int n);
 /* The generation step's GEMMs with the decoder's LayerNorms folded in (hidden size 256): RoBERTa is post-LN, so every sub-layer
  * output s is normalised once and LN(s) feeds one GEMM as A and one later residual add; at M = batch rows the consumers normalise
  * themselves instead of a LayerNorm launch per sub-layer.  ln_a != NULL: A = LN(ln_a [M,256]) (K must be 256; A is ignored);
@@ -378,8 +384,8 @@ int kzv_ocr_lstm_cell_bwd(const float* gates, const float* b_hh, const float* dh
 int kzv_ocr_log_softmax(const float* x, float* lp, int rows, int C, void* stream);
 /* nn.CTCLoss(blank, zero_infinity) on lp fp32 [T, B, C] (model.py:51-55, 171-176): d_nll[b] = -log p(target_b) (0 where infinite and
  * zero_infinity); if d_dlogits: the gradient with respect to the logits behind lp, times d_gscale[b] (the caller folds the
- * reduction -- 'mean' = 1 / (max(target_len, 1) * B) -- and the loss weight into it).  d_scratch: 2 * B * T * (2 * max_target_len + 1)
- * floats.  targets int64 [B, ld_targets]; lengths int64 [B]. */
+ * reduction -- 'mean' = 1 / (max(target_len, 1) * B) -- and the loss weight into it).  d_scratch: 2 * B * T * (2 * min(max_target_len, T) + 1)
+ * floats (a label longer than T has no alignment: loss inf -> 0 with zero_infinity, zero gradient, whatever its length; T <= 511).  targets int64 [B, ld_targets]; lengths int64 [B]. */
 int kzv_ocr_ctc(const float* lp, const int64_t* targets, int64_t ld_targets, const int64_t* input_lengths, const int64_t* target_lengths, int T,
                 int B, int C, int blank, int zero_infinity, int max_target_len, float* d_scratch, float* d_nll, const float* d_gscale,
                 float* d_dlogits, void* stream);

@@ -401,6 +401,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(const TnGroup g) 
 
 }  // namespace
 
+// K-loop schedule of the persistent 256x256 kernel: 0 eight-phase ping-pong (gemm_nt256p.hip), 1 free-running (gemm_nt256f.hip)
+static int g_nt_schedule = -1;
+static int nt_schedule() {
+    if (g_nt_schedule < 0) { const char* e = getenv("KZV_NT_FREE"); g_nt_schedule = e ? (atoi(e) != 0) : 0; }
+    return g_nt_schedule;
+}
+extern "C" int kzv_set_nt_schedule(int n) { g_nt_schedule = n < 0 ? -1 : (n != 0); return KZV_OK; }
+
 extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return kzv_fail(KZV_E_ARG, "gemm_nt: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return kzv_fail(KZV_E_ARG, "gemm_nt: empty shape");
@@ -430,6 +438,7 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     static int p_gelu = -1;      // dev knob: the two-store GELU epilogues on the persistent kernel too (A/B; default off)
     if (p_gelu < 0) { const char* e = getenv("KZV_NT256P_GELU"); p_gelu = e ? atoi(e) : 0; }
     const bool two_store = !p_gelu && (epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32);
+    if (nt_schedule() && use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256f_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
     if (use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
     if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
 #define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \

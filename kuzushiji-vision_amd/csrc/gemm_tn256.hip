@@ -48,6 +48,7 @@ template <int N> __device__ __forceinline__ void vmcnt() {
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else static_assert(N == 0, "add the vmcnt literal");
 }
 
@@ -258,6 +259,226 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TnParams p, float
     }
 }
 
+// ---- the same tile on a FREE-RUNNING schedule (round 4) ---------------------------------------------------------------------
+// gemm_nt256f.hip's schedule (read its header) carried over: all eight waves run ONE stream with two barriers per stage, every
+// wave reading the fragments of phase p + 1 between its own MFMAs of phase p (P in place of the fragment it has just used up,
+// Q into the set the other two phases do not use), the four LDS-DMA pieces of a half-tile pair between the MFMAs behind each
+// barrier, six phases ahead of their retiring vmcnt(8).  In the ping-pong kernel above the LOAD half of a barrier interval is
+// the long pole here (twice the LDS instructions of gemm_nt: 48 transposing reads per wave and stage), which is exactly what
+// this schedule takes off the critical path.
+//     p1 (P0,Q0): 8 MFMA | vmcnt, BARRIER | read Q1 (8 tr) ; 8 MFMA + the 4 DMA of {P-h0, Q-h0}(t+2)
+//     p2 (P0,Q1): 4 x [4 MFMA ; read P1[j] in place (4 tr)]
+//     p3 (P1,Q1): 8 MFMA | vmcnt, BARRIER | 8 MFMA + the 4 DMA of {Q-h1, P-h1}(t+2)
+//     p4 (P1,Q0): 4 x [4 MFMA ; read P0(t+1)[j] in place (4 tr) ; j < 2: read half of Q0(t+1) (4 tr)]
+// LDS: P half-tiles [buf][h] in the first 64 KiB, Q in the second: six per-lane fragment addresses + 16-bit immediates.
+// DMA sources: per-lane (token row, clamped column) terms fixed for the kernel (4 registers), stage / piece terms in the SGPR base.
+// A stage index past the split's last stage is clamped (it re-reads the last stage into slots nobody reads again).
+__global__ __launch_bounds__(512) void gemm_tn256f_kernel(const TnParams p, float* part_ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wr = w >> 2, wc = w & 3;
+    const int tilesN = (p.N + 255) / 256, tilesK = (p.K + 255) / 256;
+    const int per = tilesN * tilesK;
+    const int id = xcd_remap(blockIdx.x, per * p.splits);
+    const int split = id / per, rem = id - split * per;
+    const int tnb = rem / tilesK, tkb = rem - tnb * tilesK;
+    const int t_begin = split * p.chunk;                      // chunk and Mtok are multiples of 64 (launcher)
+    const int t_end = min(p.Mtok, t_begin + p.chunk);
+    const int nt = (t_end - t_begin) >> 6;                    // >= 2 (launcher)
+
+    const unsigned ldp2 = (unsigned)p.ldp * 2u, ldq2 = (unsigned)p.ldq * 2u;
+    const char* baseP = (const char*)(p.P + (int64_t)t_begin * p.ldp);
+    const char* baseQ = (const char*)(p.Q + (int64_t)t_begin * p.ldq);
+    const int64_t stepP = 64 * (int64_t)ldp2, stepQ = 64 * (int64_t)ldq2;
+    unsigned cP[2], cQ[2];                                    // piece j adds 32 token rows: in the SGPR base
+    {
+        const int r = w * 4 + (lane >> 4);
+        const int col2 = ((lane & 15) ^ ((r & 7) << 1)) * 16;                   // byte offset of this lane's 8 columns in the half-tile row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cP[h] = (unsigned)r * ldp2 + (unsigned)min((tnb * 256 + h * 128) * 2 + col2, (p.N - 8) * 2);
+            cQ[h] = (unsigned)r * ldq2 + (unsigned)min((tkb * 256 + h * 128) * 2 + col2, (p.K - 8) * 2);
+        }
+    }
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)smem) + (unsigned)w * 1024u);
+    auto stP = [&](int buf, int h, int kt, int j) {
+        const int kc = min(kt, nt - 1);
+        glds16_s(cP[h], baseP + (int64_t)kc * stepP + (int64_t)j * 32 * ldp2, ldsw + (unsigned)((buf * 2 + h) * HT_BYTES + j * 8192));
+    };
+    auto stQ = [&](int buf, int h, int kt, int j) {
+        const int kc = min(kt, nt - 1);
+        glds16_s(cQ[h], baseQ + (int64_t)kc * stepQ + (int64_t)j * 32 * ldq2, ldsw + (unsigned)(65536 + (buf * 2 + h) * HT_BYTES + j * 8192));
+    };
+
+    f32x4 acc[4][8];                                          // [k-frag][n-frag]: D rows = n (4g+r), D cols = k (l15)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposing reads: lane supplies token row 4g + (l15>>2) [+16], columns c0 + (l15&3)*4 .. +3 (gemm.hip gemm_tn)
+    const KZV_LDS char *aP[4], *aQ[2];
+    {
+        const int trow = 4 * g + (l15 >> 2);
+        const int tsw = (trow & 7) << 1;
+        const int sub8 = (l15 & 1) * 8, cq = (l15 >> 1) & 1;
+        const KZV_LDS char* sm = (const KZV_LDS char*)smem;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aP[j] = sm + trow * 256 + ((((wr * 8 + j * 2) ^ tsw) | cq) * 16) + sub8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aQ[i] = sm + 65536 + trow * 256 + ((((wc * 4 + i * 2) ^ tsw) | cq) * 16) + sub8;
+        asm volatile("" : "+v"(aP[0]), "+v"(aP[1]), "+v"(aP[2]), "+v"(aP[3]), "+v"(aQ[0]), "+v"(aQ[1]));
+    }
+    bf16x8 fp[4][2], fqX[2][2], fqY[2][2];                    // [frag][token half ks]
+    auto tr = [&](const KZV_LDS char* q) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((KZV_LDS bf16x4*)q); };
+    auto rdP = [&](int buf, int mh, int j) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int o = (buf * 2 + mh) * HT_BYTES + ks * 8192;
+            const bf16x4 lo = tr(aP[j] + o), hi = tr(aP[j] + o + 4096);
+            fp[j][ks] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+    auto rdQ = [&](int buf, int nh, int i, bf16x8 (&fq)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int o = (buf * 2 + nh) * HT_BYTES + ks * 8192;
+            const bf16x4 lo = tr(aQ[i] + o), hi = tr(aQ[i] + o + 4096);
+            fq[i][ks] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+    // two MFMAs: P fragment j, token half ks, against both Q fragments of half nh
+    auto mm2 = [&](int mh, int nh, int j, int ks, const bf16x8 (&fq)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            acc[nh * 2 + i][mh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[j][ks], fq[i][ks], acc[nh * 2 + i][mh * 4 + j], 0, 0, 0);
+    };
+    auto mm4 = [&](int mh, int nh, int j, const bf16x8 (&fq)[2][2]) { mm2(mh, nh, j, 0, fq); mm2(mh, nh, j, 1, fq); };
+
+    float bsum[8];                                            // bias gradient: see gemm_tn256_kernel
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    const bool bias_wave = p.dbias != nullptr && wc == 0;
+    auto bias_add = [&](int mh) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 u = __builtin_bit_cast(u32x4, fp[j][ks]);
+                float sacc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sacc += __uint_as_float(u[q] << 16) + __uint_as_float(u[q] & 0xffff0000u);
+                bsum[mh * 4 + j] += sacc;
+            }
+    };
+#define KZV_TSB() __builtin_amdgcn_sched_barrier(0)
+    // One stage.  Qf: the set holding Q0(t) (p1, p4); Qs: the set Q1(t) is read into (p2, p3) and, in p4, Q0(t+1).
+    auto ktile = [&](auto bufc, bf16x8 (&Qf)[2][2], bf16x8 (&Qs)[2][2], int t, bool last) {
+        constexpr int BUF = decltype(bufc)::value;
+        const bool wb = bias_wave && (t % tilesK) == tkb;
+        // ---- p1 ----
+        if (wb) bias_add(0);                                  // all of P0(t) is in fp here (p2 overwrites it fragment by fragment)
+        mm4(0, 0, 0, Qf); mm4(0, 0, 1, Qf);
+        KZV_TSB();
+        vmcnt<8>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        KZV_TSB();
+        rdQ(BUF, 1, 0, Qs); rdQ(BUF, 1, 1, Qs);
+        KZV_TSB();
+        mm2(0, 0, 2, 0, Qf); KZV_TSB(); stP(BUF, 0, t + 2, 0); KZV_TSB();
+        mm2(0, 0, 2, 1, Qf); KZV_TSB(); stP(BUF, 0, t + 2, 1); KZV_TSB();
+        mm2(0, 0, 3, 0, Qf); KZV_TSB(); stQ(BUF, 0, t + 2, 0); KZV_TSB();
+        mm2(0, 0, 3, 1, Qf); KZV_TSB(); stQ(BUF, 0, t + 2, 1); KZV_TSB();
+        // ---- p2 ----
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mm4(0, 1, j, Qs); KZV_TSB(); rdP(BUF, 1, j); KZV_TSB(); }
+        // ---- p3 ----
+        mm4(1, 1, 0, Qs); mm4(1, 1, 1, Qs);
+        KZV_TSB();
+        vmcnt<8>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        KZV_TSB();
+        if (wb) bias_add(1);                                  // all of P1(t) is in fp (read in p2, waited for above)
+        mm2(1, 1, 2, 0, Qs); KZV_TSB(); stQ(BUF, 1, t + 2, 0); KZV_TSB();
+        mm2(1, 1, 2, 1, Qs); KZV_TSB(); stQ(BUF, 1, t + 2, 1); KZV_TSB();
+        mm2(1, 1, 3, 0, Qs); KZV_TSB(); stP(BUF, 1, t + 2, 0); KZV_TSB();
+        mm2(1, 1, 3, 1, Qs); KZV_TSB(); stP(BUF, 1, t + 2, 1); KZV_TSB();
+        // ---- p4 ----
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mm4(1, 0, j, Qf);
+            KZV_TSB();
+            if (!last) { rdP(BUF ^ 1, 0, j); if (j < 2) rdQ(BUF ^ 1, 0, j, Qs); }
+            KZV_TSB();
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {                  // stages 0 and 1 (nt >= 2)
+        stP(b, 0, b, 0); stP(b, 0, b, 1); stQ(b, 0, b, 0); stQ(b, 0, b, 1);
+        stQ(b, 1, b, 0); stQ(b, 1, b, 1); stP(b, 1, b, 0); stP(b, 1, b, 1);
+    }
+    vmcnt<12>();                                   // P-h0(0), Q-h0(0) landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rdP(0, 0, j);
+    rdQ(0, 0, 0, fqX); rdQ(0, 0, 1, fqX);
+    for (int t = 0; t < nt; t += 2) {
+        ktile(I0{}, fqX, fqY, t, t + 1 >= nt);
+        if (t + 1 < nt) ktile(I1{}, fqY, fqX, t + 1, t + 2 >= nt);
+    }
+    vmcnt<0>();                                    // the refills issued past the last stage land before the epilogue reuses the ring
+#undef KZV_TSB
+
+    if (bias_wave) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = bsum[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = tnb * 256 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + l15;
+            if (g == 0 && n < p.n_store) atomicAdd(p.dbias + n, v);
+        }
+    }
+
+    // ---- epilogue: as gemm_tn256_kernel ----
+    float* tile = (float*)smem;
+    float* part = part_ws + (size_t)id * 65536;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ln = wr * 64 + j * 16 + 4 * g + r;
+                    const int k = (i >> 1) * 128 + wc * 32 + (i & 1) * 16 + l15;
+                    tile[ln * 256 + ((((k >> 2) ^ (ln & 31)) << 2) | (k & 3))] = acc[i][c * 4 + j][r];
+                }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int ln = w * 16 + it;
+            const f32x4 v = *(const f32x4*)(tile + ln * 256 + ((lane ^ (ln & 31)) << 2));
+            const int row = c * 128 + ln;
+#ifndef KZV_TN_F32_PARTIALS
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2p;
+            __builtin_nontemporal_store((u32x2p){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, (u32x2p*)((bf16_t*)part + row * 256 + lane * 4));
+#else
+            __builtin_nontemporal_store(v, (f32x4*)(part + row * 256 + lane * 4));
+#endif
+        }
+    }
+}
+
 // OUT[n][k] += sum over splits of the partial tiles (4 columns per thread, one 1-KiB row segment per wave-instruction)
 __global__ __launch_bounds__(256) void gemm_tn256_fold_kernel(const float* part_ws, float* OUT, int64_t ldo, int n_store, int K,
                                                              int tilesK, int per, int splits) {
@@ -342,6 +563,12 @@ int tn_flush(hipStream_t s) {
     return kzv_check_launch("gemm_tn256_fold");
 }
 
+// stage schedule: 0 = eight-phase ping-pong (gemm_tn256_kernel), 1 = free-running (gemm_tn256f_kernel); kzv_set_tn_schedule / KZV_TN_FREE
+int g_tn_schedule = -1;
+int tn_schedule() {
+    if (g_tn_schedule < 0) { const char* e = getenv("KZV_TN_FREE"); g_tn_schedule = e ? (atoi(e) != 0) : 1; }      // default: free-running (+10..13 % per launch, same-box A/B, bit-identical partial tiles)
+    return g_tn_schedule;
+}
 int tn256_min_tiles() {
     static int v = -1;
     // 9: the 768 x 768 outputs (attention output projection, patch embedding) take this kernel too -- 28 token splits each,
@@ -386,7 +613,12 @@ int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
     }
     float* ws = tn_partials(need, deferred ? 1 + (int)g_tn_pending.size() : 0);
     if (!ws) return 0;
-    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * splits), dim3(512), LDS_BYTES, s, p, ws);
+    if (tn_schedule()) {
+        static bool attr_f = false;
+        if (!attr_f) { (void)hipFuncSetAttribute((const void*)gemm_tn256f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_f = true; }
+        hipLaunchKernelGGL(gemm_tn256f_kernel, dim3(tiles * splits), dim3(512), LDS_BYTES, s, p, ws);
+    } else
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * splits), dim3(512), LDS_BYTES, s, p, ws);
     if (deferred) {
         g_tn_pending.push_back(TnFold{ws, p.OUT, p.ldo, p.n_store, p.K, (p.K + 255) / 256, tiles, splits, 0});
         return 1;
@@ -395,6 +627,8 @@ int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
                        (p.K + 255) / 256, tiles, splits);
     return 1;
 }
+
+extern "C" int kzv_set_tn_schedule(int n) { g_tn_schedule = n < 0 ? -1 : (n != 0); return KZV_OK; }
 
 KzvTnFoldScope::KzvTnFoldScope(hipStream_t stream) : s(stream) { ++g_tn_defer; }
 KzvTnFoldScope::~KzvTnFoldScope() { if (--g_tn_defer == 0) (void)tn_flush(s); }

@@ -602,8 +602,11 @@ extern "C" int kzv_ocr_ctc(const float* lp, const int64_t* targets, int64_t ld_t
     KZV_OCR_NULL(!lp || !input_lengths || !target_lengths || !d_scratch || !d_nll || T <= 0 || B <= 0 || C <= 0, "ocr_ctc: bad argument");
     KZV_OCR_NULL(max_target_len > 0 && !targets, "ocr_ctc: targets");
     KZV_OCR_NULL(d_dlogits && !d_gscale, "ocr_ctc: the gradient needs per-sample scales");
-    const int Smax = 2 * max_target_len + 1;
-    KZV_OCR_NULL(Smax > 1024, "ocr_ctc: targets longer than 511 characters are not supported (one thread per extended-label state)");
+    // a label longer than its input has no alignment: the kernel gives it loss inf (0 with zero_infinity) and a zero gradient before
+    // it looks at a state, so the state tables only ever hold labels of <= T characters, whatever the longest label of the batch is
+    // (ocr_lightning's whole-page texts against its length-1 sequence: nn.CTCLoss(zero_infinity=True) returns 0 there too)
+    const int Smax = 2 * (max_target_len < T ? max_target_len : T) + 1;
+    KZV_OCR_NULL(Smax > 1024, "ocr_ctc: more than 511 time steps are not supported (one thread per extended-label state)");
     int threads = 64;
     while (threads < Smax) threads <<= 1;
     hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, lp, targets, ld_targets, input_lengths, target_lengths, T, B, C, blank,

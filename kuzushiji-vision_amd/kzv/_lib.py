@@ -116,6 +116,8 @@ SYMBOLS = {
     "kzv_lerp_params": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "kzv_gemm_nt": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
     "kzv_set_rows_max_m": (C.c_int, [C.c_int]),
+    "kzv_set_nt_schedule": (C.c_int, [C.c_int]),
+    "kzv_set_tn_schedule": (C.c_int, [C.c_int]),
     "kzv_gemm_rows_ln": (C.c_int, [C.POINTER(kzv_gemm_rows_ln_args), C.c_int, _P]),
     "kzv_gemm_nt_fp8": (C.c_int, [C.POINTER(kzv_gemm_nt_fp8_args), C.c_int, _P]),
     "kzv_quant_rows_fp8": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),

@@ -384,7 +384,7 @@ class OCRModel:
             lp = torch.empty(B, nc, device=dev)
             lg = logits[:, :nc].contiguous()
             L.check(lib.kzv_ocr_log_softmax(lg.data_ptr(), lp.data_ptr(), B, nc, st), "log_softmax")
-            S = 2 * Lmax + 1
+            S = 2 * min(Lmax, 1) + 1                   # states of the labels that fit the length-1 sequence (longer ones: loss 0, no gradient)
             scratch = torch.empty(2 * B * S, device=dev)
             dl = torch.empty(B, nc, device=dev)
             L.check(lib.kzv_ocr_ctc(lp.data_ptr(), tg.data_ptr(), Lmax, il.data_ptr(), tl.data_ptr(), 1, B, nc, hp.blank_char_idx, 1, Lmax,

@@ -71,6 +71,33 @@ def test_ctc_loss_and_gradient_match_torch(lib, T, B, Cc, lens):
         assert float(nll.cpu()[[i for i, n in enumerate(lens) if n > T][0]]) == 0.0
 
 
+def test_ctc_whole_page_labels_against_a_length_one_sequence(lib):
+    """ocr_lightning's labels are whole-page texts (dataset.py) while the model emits ONE time step: every label longer than one
+    character is infeasible, and nn.CTCLoss(zero_infinity=True) gives it loss 0 and no gradient.  The launch must not be sized by
+    the longest label of the batch (a 600-character label used to be refused)."""
+    torch.manual_seed(9)
+    T, B, Cc = 1, 4, 11
+    lens = [700, 1, 0, 633]
+    Lmax = max(lens)
+    logits = torch.randn(T, B, Cc, requires_grad=True)
+    tg = torch.randint(1, Cc, (B, Lmax))
+    tl, il = torch.tensor(lens), torch.full((B,), T)
+    w = torch.rand(B) + 0.5
+    lp = F.log_softmax(logits, dim=2)
+    per = F.ctc_loss(lp, tg, il, tl, blank=0, reduction="none", zero_infinity=True)
+    (per * w).sum().backward()
+    tgd, ild, tld, wd = tg.to(DEV), il.to(DEV), tl.to(DEV), w.to(DEV)
+    dlp = lp.detach().to(DEV).contiguous()
+    scratch = torch.empty(2 * B * T * (2 * min(Lmax, T) + 1), device=DEV)          # the documented size
+    nll, g = torch.full((B,), -1.0, device=DEV), torch.full((T, B, Cc), 7.0, device=DEV)
+    L.check(lib.kzv_ocr_ctc(dlp.data_ptr(), tgd.data_ptr(), Lmax, ild.data_ptr(), tld.data_ptr(), T, B, Cc, 0, 1, Lmax,
+                            scratch.data_ptr(), nll.data_ptr(), wd.data_ptr(), g.data_ptr(), _st()), "ctc")
+    assert torch.allclose(nll.cpu(), per.detach(), atol=2e-4, rtol=1e-5)
+    assert float(nll[0]) == 0.0 and float(nll[3]) == 0.0
+    assert torch.all(g[:, 0] == 0) and torch.all(g[:, 3] == 0)
+    assert (g.cpu() - logits.grad).abs().max() < 2e-5 * max(1.0, logits.grad.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------- LSTM cell / SmoothL1 / Adam
 def test_lstm_cell_matches_nn_lstm_on_a_length_one_sequence(lib):
     """One direction of nn.LSTM on [B, 1, I] with zero state: gates from torch (fp32), cell forward and the gate gradients."""
@@ -392,6 +419,23 @@ def test_fit_steps_reduce_the_loss_and_eval_uses_running_statistics():
     out = m(batch["images"])                               # batch statistics, as during the fit: the one-character labels are fitted
     dec = [decode_ctc_output(out["pred_logits"][i].cpu(), i2c, 0) for i in range(6)]
     assert dec[0] == "a" and dec[2] == "7" and dec[4] == "q" and dec[5] == "b", dec
+
+
+def test_training_step_accepts_whole_page_label_texts():
+    """A page text of several hundred characters (what ocr_lightning's dataset yields) in the batch: the step runs, the long
+    sample contributes rec loss 0 like nn.CTCLoss(zero_infinity=True) against one time step, the short ones still train."""
+    c2i, i2c = _vocab()
+    m = OCRModel(c2i, i2c, learning_rate=1e-3, max_boxes=4, blocks=(1, 1), widths=(64, 128), init_seed=5)
+    m.configure_optimizers()
+    batch = _batch(4, 32, 48, 4, seed=3)
+    ref_loss = m.training_step(batch, 0)
+    rec_short = m.logged["train/rec_loss"][-1]
+    long_batch = dict(batch, label_texts=["a", "", "7", "abq7z" * 130], target_lengths=[1, 0, 1, 650])
+    total = m.training_step(long_batch, 0)
+    assert np.isfinite(total)
+    # samples 0 and 2 are unchanged; sample 3 ('zz' before: infeasible too) still contributes 0: the mean over the three
+    # non-empty labels is what it was
+    assert abs(m.logged["train/rec_loss"][-1] - rec_short) < 1e-5 * max(1.0, abs(rec_short)), (m.logged["train/rec_loss"], rec_short, ref_loss)
 
 
 def test_cli_trains_the_ocr_model_on_a_folder_dataset(tmp_path):
