@@ -315,6 +315,14 @@ typedef struct kzv_gemm_tn_args {
 } kzv_gemm_tn_args;
 int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream);
 
+/* The same two products on fp32 OPERANDS (A, B, P, Q are float; leading dimensions in elements, multiples of 4; K % 32 == 0 for
+ * the NT form), on the f32-input matrix instruction: exact fp32 products, fp32 accumulation (csrc/gemm_f32.hip).  For the model of
+ * ocr_lightning/model.py, which the reference trains in fp32 (ocr_lightning/train.py:132-140; its own test wants singles ==
+ * batched at 1e-6, ocr_lightning/tests/test_model.py:48-76).  kzv_gemm_nt_f32 takes the epilogues KZV_EPI_F32 and KZV_EPI_RESID
+ * (no dropout); aux is ignored.  Launches with few output tiles split the reduction; the partial tiles are summed in a fixed order. */
+int kzv_gemm_nt_f32(const kzv_gemm_nt_args* a, int epilogue, void* stream);
+int kzv_gemm_tn_f32(const kzv_gemm_tn_args* a, void* stream);
+
 /* LayerNorm over the last dim (fp32 statistics, eps inside rsqrt).  x fp32 [rows, H].
  * Replaces nn.LayerNorm in ViTLayer / RobertaLayer / heads. */
 int kzv_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
@@ -345,7 +353,11 @@ int kzv_attn_bwd(const kzv_attn_args* a, void* stream);
  * (SURVEY.md section 8(f), row N3).  Per-op entry points; the host mirror kzv/ocr_model.py strings them together the way
  * OCRModel.forward / _shared_step do (ocr_lightning/model.py:61-88, 90-195).  Activations are NHWC (rows = pixels, columns =
  * channels) so that a convolution is kzv_ocr_im2col + kzv_gemm_nt, its weight gradient kzv_gemm_tn on the same column matrix and
- * its input gradient kzv_gemm_nt against the transposed packed weight + kzv_ocr_col2im.  bf16 GEMM operands, fp32 everything else. */
+ * its input gradient kzv_gemm_nt against the transposed packed weight + kzv_ocr_col2im.  bf16 GEMM operands, fp32 everything else --
+ * or, after kzv_ocr_set_precision(1), fp32 operands throughout: every buffer documented as "bf16" below is then a float buffer of
+ * the same shape and the GEMMs are kzv_gemm_nt_f32 / kzv_gemm_tn_f32 (the reference's own arithmetic; process-wide switch, set by
+ * kzv.OCRModel before each of its passes). */
+int kzv_ocr_set_precision(int fp32);
 /* images fp32 [N, C, H, W] (ocr_collate_fn's stack, dataset.py:100) -> NHWC bf16 */
 int kzv_ocr_nchw_to_nhwc(const float* x, void* out_bf16, int N, int C, int H, int W, void* stream);
 /* nn.Conv2d forward operand (resnet34's 7x7/2, 3x3/1, 3x3/2 and 1x1/2 convolutions, model.py:31-32): cols bf16 [N*Ho*Wo, Kp],

@@ -11,25 +11,56 @@
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"
+#include <type_traits>
 
 namespace {
 
 inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// Activation / GEMM-operand element type: bf16 (the engine's MFMA path; default) or fp32 (kzv_ocr_set_precision(1): the reference
+// trains this model in fp32, and kzv.OCRModel(precision="fp32") then takes the fp32-operand GEMMs of gemm_f32.hip).  The "bf16"
+// buffers of the entry points below are float buffers in that mode; every kernel is instantiated for both.
+int g_ocr_f32 = 0;
+template <bool F32> __device__ __forceinline__ float ld1(const void* p, int64_t i) {
+    if constexpr (F32) return ((const float*)p)[i]; else return bf2f(((const bf16_t*)p)[i]);
+}
+template <bool F32> __device__ __forceinline__ void st1(void* p, int64_t i, float v) {
+    if constexpr (F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+template <bool F32> __device__ __forceinline__ f32x4 ld4(const void* p, int64_t i) {      // i % 4 == 0
+    if constexpr (F32) return *(const f32x4*)((const float*)p + i);
+    else {
+        const uint2 r = *(const uint2*)((const bf16_t*)p + i);
+        return (f32x4){bf2f((bf16_t)(r.x & 0xffffu)), bf2f((bf16_t)(r.x >> 16)), bf2f((bf16_t)(r.y & 0xffffu)), bf2f((bf16_t)(r.y >> 16))};
+    }
+}
+template <bool F32> __device__ __forceinline__ void st4(void* p, int64_t i, const f32x4& v) {
+    if constexpr (F32) *(f32x4*)((float*)p + i) = v;
+    else *(uint2*)((bf16_t*)p + i) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+}
+#define KZV_OCR_LAUNCH(kernel, grid, block, stream, ...)                                                   \
+    do {                                                                                                   \
+        if (g_ocr_f32) hipLaunchKernelGGL((kernel<true>), grid, block, 0, stream, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((kernel<false>), grid, block, 0, stream, __VA_ARGS__);                     \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------- layout / im2col
 // images fp32 [N, C, H, W] (what ocr_collate_fn stacks) -> NHWC bf16
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int N, int C, int H, int W) {
+template <bool F32>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, void* __restrict__ out, int N, int C, int H, int W) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)N * H * W) return;
     const int64_t n = t / ((int64_t)H * W), hw = t - n * H * W;
-    for (int c = 0; c < C; ++c) out[t * C + c] = f2bf(x[(n * C + c) * (int64_t)H * W + hw]);
+    for (int c = 0; c < C; ++c) st1<F32>(out, t * C + c, x[(n * C + c) * (int64_t)H * W + hw]);
 }
 
 // cols[m][(kh * KW + kw) * C + c] = x[n, ho * s - p + kh, wo * s - p + kw, c] (0 outside), m = (n * Ho + ho) * Wo + wo;
 // columns >= KH * KW * C (padding of the GEMM's K to a multiple of 64) are 0.  One thread per 8 columns.
-template <bool VEC>
-__global__ void im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ cols, int N, int H, int W, int C, int KH, int KW,
+template <bool VEC, bool F32>
+__global__ void im2col_kernel(const void* __restrict__ xv, void* __restrict__ colsv, int N, int H, int W, int C, int KH, int KW,
                               int stride, int pad, int Ho, int Wo, int Kp) {
+    using E = std::conditional_t<F32, float, bf16_t>;
+    const E* x = (const E*)xv; E* cols = (E*)colsv;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int kc = Kp >> 3;
     if (t >= (int64_t)N * Ho * Wo * kc) return;
@@ -38,12 +69,18 @@ __global__ void im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__
     const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
     const int64_t n = m / ((int64_t)Wo * Ho);
     const int K = KH * KW * C;
-    bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    E v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (E)0;
     if (VEC) {                                   // C % 8 == 0: the 8 columns share one tap
         if (k0 < K) {
             const int tap = k0 / C, c = k0 - tap * C, kh = tap / KW, kw = tap - kh * KW;
             const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
-            if (h >= 0 && h < H && w >= 0 && w < W) v = *(const bf16x8*)(x + ((n * H + h) * W + w) * C + c);
+            if (h >= 0 && h < H && w >= 0 && w < W) {
+                const E* src = x + ((n * H + h) * W + w) * C + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[j];                  // 16 / 32 contiguous bytes: vectorised by the compiler
+            }
         }
     } else {
 #pragma unroll
@@ -52,11 +89,13 @@ __global__ void im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__
             if (k < K) {
                 const int tap = k / C, c = k - tap * C, kh = tap / KW, kw = tap - kh * KW;
                 const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
-                if (h >= 0 && h < H && w >= 0 && w < W) v[j] = (short)x[((n * H + h) * W + w) * C + c];
+                if (h >= 0 && h < H && w >= 0 && w < W) v[j] = x[((n * H + h) * W + w) * C + c];
             }
         }
     }
-    *(bf16x8*)(cols + m * Kp + k0) = v;
+    E* dst = cols + m * Kp + k0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = v[j];
 }
 
 // input gradient of a convolution from the gradient of its column matrix (gather form, no atomics):
@@ -88,18 +127,19 @@ __global__ void col2im_kernel(const float* __restrict__ dcols, float* __restrict
 }
 
 // conv weight fp32 [Cout, Cin, KH, KW] (torch) -> bf16 [Cout, Kp] in (kh, kw, cin) column order, and its transpose [Kp, Cout]
-__global__ void conv_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, bf16_t* __restrict__ wpT, int Cout, int Cin,
+template <bool F32>
+__global__ void conv_weight_kernel(const float* __restrict__ w, void* __restrict__ wp, void* __restrict__ wpT, int Cout, int Cin,
                                    int KH, int KW, int Kp) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)Cout * Kp) return;
     const int o = (int)(t / Kp), k = (int)(t - (int64_t)o * Kp);
-    bf16_t v = 0;
+    float v = 0.f;
     if (k < KH * KW * Cin) {
         const int tap = k / Cin, c = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
-        v = f2bf(w[(((int64_t)o * Cin + c) * KH + kh) * KW + kw]);
+        v = w[(((int64_t)o * Cin + c) * KH + kh) * KW + kw];
     }
-    wp[t] = v;
-    if (wpT) wpT[(int64_t)k * Cout + o] = v;
+    st1<F32>(wp, t, v);
+    if (wpT) st1<F32>(wpT, (int64_t)k * Cout + o, v);
 }
 // gradient of the packed weight [Cout, Kp] -> torch layout [Cout, Cin, KH, KW] (accumulated)
 __global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gp, float* __restrict__ g, int Cout, int Cin, int KH, int KW, int Kp) {
@@ -166,9 +206,10 @@ __global__ void bn_finalize_kernel(const float* sum0, const float* sum1, float* 
     }
 }
 // a = [relu](gamma * (y - mean) * rstd + beta [+ resid]) -> bf16 (the next GEMM operand / pooling input)
+template <bool F32>
 __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, const bf16_t* __restrict__ resid,
-                                bf16_t* __restrict__ out, int64_t M, int C, int relu) {
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const void* __restrict__ resid,
+                                void* __restrict__ out, int64_t M, int C, int relu) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4n = C >> 2;
     if (t >= M * c4n) return;
@@ -176,16 +217,14 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
     const f32x4 v = *(const f32x4*)(y + t * 4), mu = *(const f32x4*)(mean + c), rs = *(const f32x4*)(rstd + c);
     const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
     f32x4 z = (v - mu) * rs * ga + be;
-    if (resid) {
-        const uint2 r = *(const uint2*)(resid + t * 4);
-        z[0] += bf2f((bf16_t)(r.x & 0xffffu)); z[1] += bf2f((bf16_t)(r.x >> 16)); z[2] += bf2f((bf16_t)(r.y & 0xffffu)); z[3] += bf2f((bf16_t)(r.y >> 16));
-    }
+    if (resid) z += ld4<F32>(resid, t * 4);
     if (relu) { z[0] = fmaxf(z[0], 0.f); z[1] = fmaxf(z[1], 0.f); z[2] = fmaxf(z[2], 0.f); z[3] = fmaxf(z[3], 0.f); }
-    *(uint2*)(out + t * 4) = make_uint2(pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]));
+    st4<F32>(out, t * 4, z);
 }
 // backward, pass 1: dz = da (* (a > 0) if relu); dbeta += sum dz, dgamma += sum dz * xhat; dz written (fp32) for pass 2 and for
 // the residual branch.  Same block decomposition as bn_colsum_kernel.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const bf16_t* __restrict__ a, const float* __restrict__ y,
+template <bool F32>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const void* __restrict__ a, const float* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dz,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int C, int relu,
                                                             int rows_per_block) {
@@ -200,11 +239,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (int64_t r = r0 + slice; r < r1; r += tpc) {
             f32x4 g = *(const f32x4*)(da + r * C + c);
             if (relu) {
-                const uint2 av = *(const uint2*)(a + r * C + c);
-                if (!(av.x & 0x7fffu)) g[0] = 0.f;
-                if (!(av.x & 0x7fff0000u)) g[1] = 0.f;
-                if (!(av.y & 0x7fffu)) g[2] = 0.f;
-                if (!(av.y & 0x7fff0000u)) g[3] = 0.f;
+                const f32x4 av = ld4<F32>(a, r * C + c);                 // the ReLU output: gradient flows where it is non-zero
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (av[q] == 0.f) g[q] = 0.f;
             }
             *(f32x4*)(dz + r * C + c) = g;
             const f32x4 xh = (*(const f32x4*)(y + r * C + c) - mu) * rs;
@@ -230,9 +267,10 @@ __global__ void bn_bwd_totals_kernel(const float* __restrict__ pg, const float* 
     dgamma[c] += g; dbeta[c] += b;
 }
 // pass 2: dy = gamma * rstd * (dz - dbeta / M - xhat * dgamma / M) (train) or gamma * rstd * dz (eval) -> bf16 (GEMM operand)
+template <bool F32>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, bf16_t* __restrict__ dy, int64_t M, int C, int train) {
+                                    const float* __restrict__ dbeta, void* __restrict__ dy, int64_t M, int C, int train) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4n = C >> 2;
     if (t >= M * c4n) return;
@@ -245,12 +283,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
         r = g - *(const f32x4*)(dbeta + c) * im - xh * *(const f32x4*)(dgamma + c) * im;
     }
     r = r * ga * rs;
-    *(uint2*)(dy + t * 4) = make_uint2(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]));
+    st4<F32>(dy, t * 4, r);
 }
 
 // ---------------------------------------------------------------------------------------------- pooling
 // MaxPool2d(3, stride 2, padding 1) on NHWC bf16; idx = winning tap (kh * 3 + kw), first maximum like torch
-__global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, unsigned char* __restrict__ idx, int N, int H, int W,
+template <bool F32>
+__global__ void maxpool_fwd_kernel(const void* __restrict__ x, void* __restrict__ out, unsigned char* __restrict__ idx, int N, int H, int W,
                                    int C, int Ho, int Wo) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)N * Ho * Wo * C) return;
@@ -263,10 +302,10 @@ __global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
         for (int kw = 0; kw < 3; ++kw) {
             const int h = ho * 2 - 1 + kh, w = wo * 2 - 1 + kw;
             if (h < 0 || h >= H || w < 0 || w >= W) continue;
-            const float v = bf2f(x[((n * H + h) * W + w) * C + c]);
+            const float v = ld1<F32>(x, ((n * H + h) * W + w) * C + c);
             if (v > best) { best = v; bi = kh * 3 + kw; }
         }
-    out[t] = f2bf(best); idx[t] = (unsigned char)bi;
+    st1<F32>(out, t, best); idx[t] = (unsigned char)bi;
 }
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx, float* __restrict__ dx, int N, int H, int W,
                                    int C, int Ho, int Wo) {
@@ -290,14 +329,15 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const unsigne
     dx[t] = acc;
 }
 // AdaptiveAvgPool2d((1, 1)) + flatten: feat[n][c] = mean over the HW pixels; fp32 and bf16 copies
-__global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, float* __restrict__ f32, bf16_t* __restrict__ f16, int N, int HW, int C) {
+template <bool F32>
+__global__ void avgpool_fwd_kernel(const void* __restrict__ x, float* __restrict__ f32, void* __restrict__ f16, int N, int HW, int C) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N * C) return;
     const int n = t / C, c = t - n * C;
     float s = 0.f;
-    for (int i = 0; i < HW; ++i) s += bf2f(x[((int64_t)n * HW + i) * C + c]);
+    for (int i = 0; i < HW; ++i) s += ld1<F32>(x, ((int64_t)n * HW + i) * C + c);
     s /= (float)HW;
-    f32[t] = s; f16[t] = f2bf(s);
+    f32[t] = s; st1<F32>(f16, t, s);
 }
 __global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx, int N, int HW, int C) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,7 +351,8 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, float* __res
 // gates fp32 [B, 4H] = x W_ih^T + b_ih (b_hh [4H] is added here) in torch's order (i, f, g, o); h0 = c0 = 0 (the reference feeds a length-1 sequence,
 // model.py:73-75), so c = sigmoid(i) * tanh(g), h = sigmoid(o) * tanh(c); W_hh never sees a non-zero operand.
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
-__global__ void lstm_cell_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ bhh, float* __restrict__ h32, bf16_t* __restrict__ h16,
+template <bool F32>
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ bhh, float* __restrict__ h32, void* __restrict__ h16,
                                      int64_t ldh, int B, int Hh) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * Hh) return;
@@ -319,11 +360,12 @@ __global__ void lstm_cell_fwd_kernel(const float* __restrict__ gates, const floa
     const float* g = gates + (int64_t)b * 4 * Hh;
     const float c = sigm(g[j] + bhh[j]) * tanhf(g[2 * Hh + j] + bhh[2 * Hh + j]);
     const float h = sigm(g[3 * Hh + j] + bhh[3 * Hh + j]) * tanhf(c);
-    h32[(int64_t)b * ldh + j] = h; h16[(int64_t)b * ldh + j] = f2bf(h);
+    h32[(int64_t)b * ldh + j] = h; st1<F32>(h16, (int64_t)b * ldh + j, h);
 }
 // dgates (bf16, GEMM operand) from dh: the forget gate receives no gradient (c0 = 0)
+template <bool F32>
 __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ bhh, const float* __restrict__ dh, int64_t lddh,
-                                     bf16_t* __restrict__ dg, int B, int Hh) {
+                                     void* __restrict__ dg, int B, int Hh) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * Hh) return;
     const int b = t / Hh, j = t - b * Hh;
@@ -331,11 +373,11 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const floa
     const float i = sigm(g[j] + bhh[j]), gg = tanhf(g[2 * Hh + j] + bhh[2 * Hh + j]), o = sigm(g[3 * Hh + j] + bhh[3 * Hh + j]);
     const float c = i * gg, tc = tanhf(c), d = dh[(int64_t)b * lddh + j];
     const float dc = d * o * (1.f - tc * tc);
-    bf16_t* q = dg + (int64_t)b * 4 * Hh;
-    q[j] = f2bf(dc * gg * i * (1.f - i));
-    q[Hh + j] = 0;
-    q[2 * Hh + j] = f2bf(dc * i * (1.f - gg * gg));
-    q[3 * Hh + j] = f2bf(d * tc * o * (1.f - o));
+    const int64_t q = (int64_t)b * 4 * Hh;
+    st1<F32>(dg, q + j, dc * gg * i * (1.f - i));
+    st1<F32>(dg, q + Hh + j, 0.f);
+    st1<F32>(dg, q + 2 * Hh + j, dc * i * (1.f - gg * gg));
+    st1<F32>(dg, q + 3 * Hh + j, d * tc * o * (1.f - o));
 }
 
 // ---------------------------------------------------------------------------------------------- log_softmax + CTC
@@ -479,25 +521,29 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     m[t] = mm; v[t] = vv;
     p[t] -= (lr / bc1) * mm / (sqrtf(vv) / sqrt_bc2 + eps);
 }
-__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int64_t n) {
+template <bool F32>
+__global__ void cast_bf16_kernel(const float* __restrict__ x, void* __restrict__ out, int64_t n) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[t] = f2bf(x[t]);
+    if (t < n) st1<F32>(out, t, x[t]);
 }
 // [R, Cc] fp32 -> its bf16 transpose [Cc, R] (input-gradient GEMMs of the small Linear / LSTM weights)
-__global__ void cast_transpose_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int R, int Cc) {
+template <bool F32>
+__global__ void cast_transpose_kernel(const float* __restrict__ x, void* __restrict__ out, int R, int Cc) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)R * Cc) return;
     const int r = (int)(t / Cc), c = (int)(t - (int64_t)r * Cc);
-    out[(int64_t)c * R + r] = f2bf(x[t]);
+    st1<F32>(out, (int64_t)c * R + r, x[t]);
 }
 
 }  // namespace
 
 #define KZV_OCR_NULL(cond, what) do { if (cond) return kzv_fail(KZV_E_ARG, what); } while (0)
 
+extern "C" int kzv_ocr_set_precision(int fp32) { g_ocr_f32 = fp32 != 0; return KZV_OK; }
+
 extern "C" int kzv_ocr_nchw_to_nhwc(const float* x, void* out_bf16, int N, int C, int H, int W, void* stream) {
     KZV_OCR_NULL(!x || !out_bf16 || N <= 0 || C <= 0 || H <= 0 || W <= 0, "ocr_nchw_to_nhwc: bad argument");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((int64_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out_bf16, N, C, H, W);
+    KZV_OCR_LAUNCH(nchw_to_nhwc_kernel, dim3(nblk((int64_t)N * H * W, 256)), dim3(256), (hipStream_t)stream, x, out_bf16, N, C, H, W);
     return kzv_check_launch("ocr_nchw_to_nhwc");
 }
 extern "C" int kzv_ocr_im2col(const void* x, void* cols, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kp, void* stream) {
@@ -505,8 +551,10 @@ extern "C" int kzv_ocr_im2col(const void* x, void* cols, int N, int H, int W, in
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     KZV_OCR_NULL(Ho <= 0 || Wo <= 0, "ocr_im2col: empty output");
     const int64_t total = (int64_t)N * Ho * Wo * (Kp / 8);
-    if (C % 8 == 0) hipLaunchKernelGGL(im2col_kernel<true>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)cols, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp);
-    else hipLaunchKernelGGL(im2col_kernel<false>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)cols, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp);
+#define KZV_IM2COL(V, F) hipLaunchKernelGGL((im2col_kernel<V, F>), dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cols, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kp)
+    if (C % 8 == 0) { if (g_ocr_f32) KZV_IM2COL(true, true); else KZV_IM2COL(true, false); }
+    else { if (g_ocr_f32) KZV_IM2COL(false, true); else KZV_IM2COL(false, false); }
+#undef KZV_IM2COL
     return kzv_check_launch("ocr_im2col");
 }
 extern "C" int kzv_ocr_col2im(const float* dcols, float* dx, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int Kp, int accumulate, void* stream) {
@@ -517,7 +565,7 @@ extern "C" int kzv_ocr_col2im(const float* dcols, float* dx, int N, int H, int W
 }
 extern "C" int kzv_ocr_conv_weight(const float* w, void* wp, void* wpT, int Cout, int Cin, int KH, int KW, int Kp, void* stream) {
     KZV_OCR_NULL(!w || !wp || Kp < KH * KW * Cin, "ocr_conv_weight: bad argument");
-    hipLaunchKernelGGL(conv_weight_kernel, dim3(nblk((int64_t)Cout * Kp, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wp, (bf16_t*)wpT, Cout, Cin, KH, KW, Kp);
+    KZV_OCR_LAUNCH(conv_weight_kernel, dim3(nblk((int64_t)Cout * Kp, 256)), dim3(256), (hipStream_t)stream, w, wp, wpT, Cout, Cin, KH, KW, Kp);
     return kzv_check_launch("ocr_conv_weight");
 }
 extern "C" int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, int Cin, int KH, int KW, int Kp, void* stream) {
@@ -543,7 +591,7 @@ extern "C" int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gam
         hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, part, d_scratch + C, nb, C);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, d_scratch, d_scratch ? d_scratch + C : nullptr, mean, rstd, run_mean, run_var, C, M, eps, momentum, train);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), 0, s, y, mean, rstd, gamma, beta, (const bf16_t*)resid_bf16, (bf16_t*)out_bf16, M, C, relu);
+    KZV_OCR_LAUNCH(bn_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), s, y, mean, rstd, gamma, beta, resid_bf16, out_bf16, M, C, relu);
     return kzv_check_launch("ocr_bn_fwd");
 }
 extern "C" int kzv_ocr_bn_bwd(const float* da, const void* a_bf16, const float* y, int64_t M, int C, const float* mean, const float* rstd,
@@ -554,15 +602,15 @@ extern "C" int kzv_ocr_bn_bwd(const float* da, const void* a_bf16, const float* 
     const int rpb = 256, nb = (int)nblk(M, rpb);
     float* tot = d_scratch;                                    // [2, C]: this launch's dgamma | dbeta (the second pass needs them complete)
     float* pg = d_scratch + 2 * C; float* pb = pg + (int64_t)nb * C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, s, da, (const bf16_t*)a_bf16, y, mean, rstd, dz, pg, pb, M, C, relu, rpb);
+    KZV_OCR_LAUNCH(bn_bwd_reduce_kernel, dim3(nb), dim3(256), s, da, a_bf16, y, mean, rstd, dz, pg, pb, M, C, relu, rpb);
     hipLaunchKernelGGL(bn_bwd_totals_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, pg, pb, tot, dgamma, dbeta, nb, C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), 0, s, dz, y, mean, rstd, gamma, tot, tot + C, (bf16_t*)dy_bf16, M, C, train);
+    KZV_OCR_LAUNCH(bn_bwd_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), s, dz, y, mean, rstd, gamma, tot, tot + C, dy_bf16, M, C, train);
     return kzv_check_launch("ocr_bn_bwd");
 }
 extern "C" int kzv_ocr_maxpool_fwd(const void* x, void* out, unsigned char* idx, int N, int H, int W, int C, void* stream) {
     KZV_OCR_NULL(!x || !out || !idx, "ocr_maxpool_fwd: null");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk((int64_t)N * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, idx, N, H, W, C, Ho, Wo);
+    KZV_OCR_LAUNCH(maxpool_fwd_kernel, dim3(nblk((int64_t)N * Ho * Wo * C, 256)), dim3(256), (hipStream_t)stream, x, out, idx, N, H, W, C, Ho, Wo);
     return kzv_check_launch("ocr_maxpool_fwd");
 }
 extern "C" int kzv_ocr_maxpool_bwd(const float* dout, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream) {
@@ -573,7 +621,7 @@ extern "C" int kzv_ocr_maxpool_bwd(const float* dout, const unsigned char* idx, 
 }
 extern "C" int kzv_ocr_avgpool_fwd(const void* x, float* f32, void* f16, int N, int HW, int C, void* stream) {
     KZV_OCR_NULL(!x || !f32 || !f16 || HW <= 0, "ocr_avgpool_fwd: bad argument");
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(nblk((int64_t)N * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, f32, (bf16_t*)f16, N, HW, C);
+    KZV_OCR_LAUNCH(avgpool_fwd_kernel, dim3(nblk((int64_t)N * C, 256)), dim3(256), (hipStream_t)stream, x, f32, f16, N, HW, C);
     return kzv_check_launch("ocr_avgpool_fwd");
 }
 extern "C" int kzv_ocr_avgpool_bwd(const float* dfeat, float* dx, int N, int HW, int C, void* stream) {
@@ -583,12 +631,12 @@ extern "C" int kzv_ocr_avgpool_bwd(const float* dfeat, float* dx, int N, int HW,
 }
 extern "C" int kzv_ocr_lstm_cell_fwd(const float* gates, const float* b_hh, float* h32, void* h16, int64_t ldh, int B, int Hh, void* stream) {
     KZV_OCR_NULL(!gates || !b_hh || !h32 || !h16 || B <= 0 || Hh <= 0, "ocr_lstm_cell_fwd: bad argument");
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(nblk((int64_t)B * Hh, 256)), dim3(256), 0, (hipStream_t)stream, gates, b_hh, h32, (bf16_t*)h16, ldh, B, Hh);
+    KZV_OCR_LAUNCH(lstm_cell_fwd_kernel, dim3(nblk((int64_t)B * Hh, 256)), dim3(256), (hipStream_t)stream, gates, b_hh, h32, h16, ldh, B, Hh);
     return kzv_check_launch("ocr_lstm_cell_fwd");
 }
 extern "C" int kzv_ocr_lstm_cell_bwd(const float* gates, const float* b_hh, const float* dh, int64_t lddh, void* dgates_bf16, int B, int Hh, void* stream) {
     KZV_OCR_NULL(!gates || !b_hh || !dh || !dgates_bf16, "ocr_lstm_cell_bwd: null");
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(nblk((int64_t)B * Hh, 256)), dim3(256), 0, (hipStream_t)stream, gates, b_hh, dh, lddh, (bf16_t*)dgates_bf16, B, Hh);
+    KZV_OCR_LAUNCH(lstm_cell_bwd_kernel, dim3(nblk((int64_t)B * Hh, 256)), dim3(256), (hipStream_t)stream, gates, b_hh, dh, lddh, dgates_bf16, B, Hh);
     return kzv_check_launch("ocr_lstm_cell_bwd");
 }
 extern "C" int kzv_ocr_log_softmax(const float* x, float* lp, int rows, int C, void* stream) {
@@ -627,11 +675,11 @@ extern "C" int kzv_ocr_adam(float* p, const float* g, float* m, float* v, int64_
 }
 extern "C" int kzv_ocr_cast_bf16(const float* x, void* out, int64_t n, void* stream) {
     KZV_OCR_NULL(!x || !out || n <= 0, "ocr_cast_bf16: bad argument");
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, n);
+    KZV_OCR_LAUNCH(cast_bf16_kernel, dim3(nblk(n, 256)), dim3(256), (hipStream_t)stream, x, out, n);
     return kzv_check_launch("ocr_cast_bf16");
 }
 extern "C" int kzv_ocr_cast_transpose(const float* x, void* out, int R, int Cc, void* stream) {
     KZV_OCR_NULL(!x || !out || R <= 0 || Cc <= 0, "ocr_cast_transpose: bad argument");
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3(nblk((int64_t)R * Cc, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out, R, Cc);
+    KZV_OCR_LAUNCH(cast_transpose_kernel, dim3(nblk((int64_t)R * Cc, 256)), dim3(256), (hipStream_t)stream, x, out, R, Cc);
     return kzv_check_launch("ocr_cast_transpose");
 }

@@ -134,6 +134,9 @@ SYMBOLS = {
     "kzv_debug_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "kzv_debug_attn_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     # ---- ocr_lightning/model.py path (csrc/ocr.hip)
+    "kzv_gemm_nt_f32": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
+    "kzv_gemm_tn_f32": (C.c_int, [C.POINTER(kzv_gemm_tn_args), _P]),
+    "kzv_ocr_set_precision": (C.c_int, [C.c_int]),
     "kzv_ocr_nchw_to_nhwc": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "kzv_ocr_im2col": (C.c_int, [_P, _P] + [C.c_int] * 9 + [_P]),
     "kzv_ocr_col2im": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),

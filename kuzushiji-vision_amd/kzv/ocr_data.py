@@ -12,36 +12,39 @@ CHAR_TO_IDX = {char: idx for idx, char in enumerate(VOCAB)}
 IDX_TO_CHAR = {idx: char for idx, char in enumerate(VOCAB)}
 
 
+_IMAGE_SUFFIXES = {".png", ".jpg", ".jpeg"}
+# sidecar files of a page image: (sub-directory of the split, suffix, what the reference calls it when it is missing)
+_SIDECARS = (("labels", ".txt", "Label file"), ("bounding_boxes", ".json", "Bounding box file"))
+
+
+def _page_samples(split_dir):
+    """Yield (image, label, boxes) path triples of one split: <split>/images/<book>/<page>.<png|jpg|jpeg> together with
+    <split>/labels/<book>/<page>.txt and <split>/bounding_boxes/<book>/<page>.json, in directory-listing order (dataset.py:14-44).
+    A page that lacks a sidecar is reported with the reference's warning and left out."""
+    from pathlib import Path
+    root = Path(split_dir)
+    for book in (root / "images").iterdir():
+        if not book.is_dir():
+            continue
+        for page in book.iterdir():
+            if page.suffix.lower() not in _IMAGE_SUFFIXES:
+                continue
+            sidecars = [root / sub / book.name / (page.stem + suffix) for sub, suffix, _ in _SIDECARS]
+            missing = next((what for path, (_, _, what) in zip(sidecars, _SIDECARS) if not path.exists()), None)
+            if missing is not None:
+                print(f"Warning: {missing} not found for image {page}, skipping sample.")
+                continue
+            yield (str(page), *map(str, sidecars))
+
+
 class OcrDataset:
-    """images/<book>/*.png|jpg|jpeg with labels/<book>/<name>.txt and bounding_boxes/<book>/<name>.json (dataset.py:14-44);
-    samples whose label or box file is missing are skipped with the reference's warning."""
+    """Folder dataset of ocr_lightning/dataset.py: same constructor, ``file_samples`` triples, ``__getitem__`` dict and skipping rule."""
 
     def __init__(self, data_split_dir, image_transforms=None, char_to_idx=None):
         self.data_split_dir = str(data_split_dir)
         self.image_transforms = image_transforms
         self.char_to_idx = char_to_idx
-        self.file_samples = []
-        images_dir = os.path.join(self.data_split_dir, "images")
-        labels_dir = os.path.join(self.data_split_dir, "labels")
-        boxes_dir = os.path.join(self.data_split_dir, "bounding_boxes")
-        for book_id in os.listdir(images_dir):
-            book_images_dir = os.path.join(images_dir, book_id)
-            if not os.path.isdir(book_images_dir):
-                continue
-            for image_name in os.listdir(book_images_dir):
-                if not image_name.lower().endswith((".png", ".jpg", ".jpeg")):
-                    continue
-                image_path = os.path.join(book_images_dir, image_name)
-                base = os.path.splitext(image_name)[0]
-                label_path = os.path.join(labels_dir, book_id, f"{base}.txt")
-                bbox_path = os.path.join(boxes_dir, book_id, f"{base}.json")
-                if not os.path.exists(label_path):
-                    print(f"Warning: Label file not found for image {image_path}, skipping sample.")
-                    continue
-                if not os.path.exists(bbox_path):
-                    print(f"Warning: Bounding box file not found for image {image_path}, skipping sample.")
-                    continue
-                self.file_samples.append((image_path, label_path, bbox_path))
+        self.file_samples = list(_page_samples(self.data_split_dir))
 
     def __len__(self):
         return len(self.file_samples)

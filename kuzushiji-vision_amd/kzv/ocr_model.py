@@ -16,8 +16,10 @@ What differs, and why:
     unless a state_dict is loaded.  The TOPOLOGY is restated from the published ResNet34 (BasicBlock x (3, 4, 6, 3), widths 64..512):
     parity of the trunk is pinned against torch's own Conv2d / BatchNorm2d / MaxPool2d modules composed the same way
     (oracle/ocr_oracle.py), not against torchvision -- "unpinned" in that one respect.
-  * precision: the reference trains this model in fp32 (pl.Trainer default); here the GEMM operands are bf16 with fp32 accumulation
-    (the engine's MFMA path), everything else fp32 -- tolerances in the tests are the bf16 ones.
+  * precision: the reference trains this model in fp32 (pl.Trainer default).  ``precision="fp32"`` is that arithmetic: fp32
+    activations and GEMM operands on the f32-input matrix instruction (csrc/gemm_f32.hip: exact fp32 products, fp32 accumulation),
+    the tests hold it to fp32 tolerances.  ``precision="bf16"`` (the default of round 3, kept for speed) rounds the GEMM operands to
+    bf16 with fp32 accumulation (the engine's MFMA path) -- narrower than the reference, tolerances are the bf16 ones.
 """
 from __future__ import annotations
 
@@ -48,10 +50,15 @@ class _Conv:
 
 class OCRModel:
     def __init__(self, char_to_idx, idx_to_char, learning_rate=1e-4, max_boxes=50, blocks=RESNET34_BLOCKS, widths=RESNET34_WIDTHS,
-                 device="cuda", init_seed=0):
+                 device="cuda", init_seed=0, precision="fp32"):
         import torch
         self.lib = L.load()                     # raises without libkzv.so: no CPU path
         self.device = torch.device(device)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 GEMM operands)")
+        self.precision = precision
+        self.f32 = precision == "fp32"
+        self.adt = torch.float32 if self.f32 else torch.bfloat16           # activations / GEMM operands
         num_chars = len(char_to_idx)
         blank = char_to_idx.get("<blank>", 0)   # model.py:15
         if blank != 0 and list(char_to_idx.keys())[0] != "<blank>":
@@ -178,9 +185,10 @@ class OCRModel:
         """bf16 copies of every GEMM operand: packed [Cout, Kp] (+ transposed) conv weights, Linear / LSTM weights and their transposes."""
         import torch
         lib, st = self.lib, L.stream_handle()
+        self._set_precision()
         for c in self.convs:
-            wp = self._w16.setdefault(c.conv_key, torch.empty(c.cout, c.Kp, dtype=torch.bfloat16, device=self.device))
-            wt = self._w16.setdefault(c.conv_key + ".T", torch.empty(c.Kp, c.cout, dtype=torch.bfloat16, device=self.device))
+            wp = self._w16.setdefault(c.conv_key, torch.empty(c.cout, c.Kp, dtype=self.adt, device=self.device))
+            wt = self._w16.setdefault(c.conv_key + ".T", torch.empty(c.Kp, c.cout, dtype=self.adt, device=self.device))
             L.check(lib.kzv_ocr_conv_weight(self.param(c.conv_key + ".weight").data_ptr(), wp.data_ptr(), wt.data_ptr(), c.cout, c.cin, c.k, c.k, c.Kp, st), "conv_weight")
         for name, (o, shp) in self.offsets.items():
             if len(shp) != 2 or "weight_hh" in name:
@@ -189,8 +197,8 @@ class OCRModel:
             rp = _r64(rows) if name == "recognition_fc.weight" else rows
             w = self._w16.get(name)
             if w is None:
-                w = self._w16[name] = torch.zeros(rp, cols, dtype=torch.bfloat16, device=self.device)
-                self._w16[name + ".T"] = torch.zeros(cols, rp, dtype=torch.bfloat16, device=self.device)
+                w = self._w16[name] = torch.zeros(rp, cols, dtype=self.adt, device=self.device)
+                self._w16[name + ".T"] = torch.zeros(cols, rp, dtype=self.adt, device=self.device)
             L.check(lib.kzv_ocr_cast_bf16(self.param(name).data_ptr(), w.data_ptr(), rows * cols, st), "cast")
             if rp == rows:
                 L.check(lib.kzv_ocr_cast_transpose(self.param(name).data_ptr(), self._w16[name + ".T"].data_ptr(), rows, cols, st), "cast_T")
@@ -217,17 +225,21 @@ class OCRModel:
     def __call__(self, images):
         return self.forward(images)
 
+    def _set_precision(self):
+        """The element type of the library's OCR kernels is a process-wide switch: set it before every pass of this model."""
+        L.check(self.lib.kzv_ocr_set_precision(1 if self.f32 else 0), "ocr_set_precision")
+
     # ------------------------------------------------------------------------------------------------ GEMM helpers
     def _gemm_nt(self, A, B16, Cout, M, N, K, epi, bias=None, resid=None, n_valid=0):
         a = L.kzv_gemm_nt_args(A=A.data_ptr(), lda=A.stride(0), B=B16.data_ptr(), ldb=B16.stride(0), C=Cout.data_ptr(), ldc=Cout.stride(0),
                                bias=None if bias is None else bias.data_ptr(), resid=None if resid is None else resid.data_ptr(),
                                ldr=0 if resid is None else resid.stride(0), aux=None, ldaux=0, M=M, N=N, K=K, n_valid=n_valid, drop_p=0.0, drop_key=0)
-        L.check(self.lib.kzv_gemm_nt(C.byref(a), epi, L.stream_handle()), "gemm_nt")
+        L.check((self.lib.kzv_gemm_nt_f32 if self.f32 else self.lib.kzv_gemm_nt)(C.byref(a), epi, L.stream_handle()), "gemm_nt")
 
     def _gemm_tn(self, P16, Q16, OUT, Mtok, N, K, n_store=0, dbias=None):
         a = L.kzv_gemm_tn_args(P=P16.data_ptr(), ldp=P16.stride(0), Q=Q16.data_ptr(), ldq=Q16.stride(0), OUT=OUT.data_ptr(), ldo=OUT.stride(0),
                                Mtok=Mtok, N=N, K=K, n_store=n_store, dbias=None if dbias is None else dbias.data_ptr())
-        L.check(self.lib.kzv_gemm_tn(C.byref(a), L.stream_handle()), "gemm_tn")
+        L.check((self.lib.kzv_gemm_tn_f32 if self.f32 else self.lib.kzv_gemm_tn)(C.byref(a), L.stream_handle()), "gemm_tn")
 
     # ------------------------------------------------------------------------------------------------ forward
     def _conv_bn(self, c: _Conv, x16, N, H, W, relu, resid16=None, keep=None):
@@ -236,12 +248,12 @@ class OCRModel:
         lib, st, dev = self.lib, L.stream_handle(), self.device
         Ho, Wo = (H + 2 * c.pad - c.k) // c.stride + 1, (W + 2 * c.pad - c.k) // c.stride + 1
         M = N * Ho * Wo
-        cols = torch.empty(M, c.Kp, dtype=torch.bfloat16, device=dev)
+        cols = torch.empty(M, c.Kp, dtype=self.adt, device=dev)
         L.check(lib.kzv_ocr_im2col(x16.data_ptr(), cols.data_ptr(), N, H, W, c.cin, c.k, c.k, c.stride, c.pad, c.Kp, st), "im2col")
         y = torch.empty(M, c.cout, dtype=torch.float32, device=dev)
         self._gemm_nt(cols, self._w16[c.conv_key], y, M, c.cout, c.Kp, L.EPI_F32)
         mean, rstd = torch.empty(c.cout, device=dev), torch.empty(c.cout, device=dev)
-        out = torch.empty(M, c.cout, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(M, c.cout, dtype=self.adt, device=dev)
         scratch = torch.empty(lib.kzv_ocr_bn_scratch_floats(M, c.cout), device=dev)
         L.check(lib.kzv_ocr_bn_fwd(y.data_ptr(), M, c.cout, self.param(c.bn_key + ".weight").data_ptr(), self.param(c.bn_key + ".bias").data_ptr(),
                                    self.buffers[c.bn_key + ".running_mean"].data_ptr(), self.buffers[c.bn_key + ".running_var"].data_ptr(),
@@ -259,12 +271,12 @@ class OCRModel:
         N, Cc, H, W = images.shape
         if Cc != 3:
             raise ValueError(f"images must be [B, 3, H, W], got {tuple(images.shape)}")
-        x = torch.empty(N * H * W, 3, dtype=torch.bfloat16, device=dev)
+        x = torch.empty(N * H * W, 3, dtype=self.adt, device=dev)
         L.check(lib.kzv_ocr_nchw_to_nhwc(images.data_ptr(), x.data_ptr(), N, 3, H, W, st), "nhwc")
         k = {}
         a, H1, W1 = self._conv_bn(self.stem, x, N, H, W, True, keep=k)
         Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        pooled = torch.empty(N * Hp * Wp, self.stem.cout, dtype=torch.bfloat16, device=dev)
+        pooled = torch.empty(N * Hp * Wp, self.stem.cout, dtype=self.adt, device=dev)
         idx = torch.empty(N * Hp * Wp, self.stem.cout, dtype=torch.uint8, device=dev)
         L.check(lib.kzv_ocr_maxpool_fwd(a.data_ptr(), pooled.data_ptr(), idx.data_ptr(), N, H1, W1, self.stem.cout, st), "maxpool")
         tape.append(("stem", k, idx, (H1, W1, Hp, Wp)))
@@ -286,10 +298,11 @@ class OCRModel:
         import torch
         lib, st, dev = self.lib, L.stream_handle(), self.device
         images = images.to(dev, torch.float32).contiguous()
+        self._set_precision()
         tape = _tape if _tape is not None else []
         act, N, Hc, Wc = self._trunk(images, tape)
         feat32 = torch.empty(N, self.feat, device=dev)
-        feat16 = torch.empty(N, self.feat, dtype=torch.bfloat16, device=dev)
+        feat16 = torch.empty(N, self.feat, dtype=self.adt, device=dev)
         L.check(lib.kzv_ocr_avgpool_fwd(act.data_ptr(), feat32.data_ptr(), feat16.data_ptr(), N, Hc * Wc, self.feat, st), "avgpool")
         mb4 = self.hparams.max_boxes * 4
         boxes = torch.empty(N, mb4, device=dev)
@@ -300,7 +313,7 @@ class OCRModel:
         for layer in range(2):
             K = x16.shape[1]
             h32 = torch.empty(N, 2 * LSTM_HIDDEN, device=dev)
-            h16 = torch.empty(N, 2 * LSTM_HIDDEN, dtype=torch.bfloat16, device=dev)
+            h16 = torch.empty(N, 2 * LSTM_HIDDEN, dtype=self.adt, device=dev)
             gates_l = []
             for d, sfx in enumerate(("", "_reverse")):
                 nm = f"recognition_rnn.weight_ih_l{layer}{sfx}"
@@ -414,6 +427,7 @@ class OCRModel:
         """Hand-written backward of the last _shared_step (what ``loss.backward()`` does for the reference): fills ``flat_grads``."""
         import torch
         lib, st, dev = self.lib, L.stream_handle(), self.device
+        self._set_precision()
         tape, dboxes, dlogits = self._pending
         head = tape[-1][1]
         N, Hc, Wc = head["geom"]
@@ -431,7 +445,7 @@ class OCRModel:
             K = x16.shape[1]
             dx = None
             for d, sfx in enumerate(("", "_reverse")):
-                dg = torch.empty(N, 4 * LSTM_HIDDEN, dtype=torch.bfloat16, device=dev)
+                dg = torch.empty(N, 4 * LSTM_HIDDEN, dtype=self.adt, device=dev)
                 bhh = self.param(f"recognition_rnn.bias_hh_l{layer}{sfx}")
                 L.check(lib.kzv_ocr_lstm_cell_bwd(gates_l[d].data_ptr(), bhh.data_ptr(), dh[:, d * LSTM_HIDDEN:].data_ptr(), H2, dg.data_ptr(), N, LSTM_HIDDEN, st), "lstm_bwd")
                 nm = f"recognition_rnn.weight_ih_l{layer}{sfx}"
@@ -450,11 +464,11 @@ class OCRModel:
         mb4 = self.hparams.max_boxes * 4
         mb4p = _r64(mb4)
         if mb4p != mb4:
-            pad = torch.zeros(N, mb4p, dtype=torch.bfloat16, device=dev); pad[:, :mb4].copy_(db16); db16 = pad
+            pad = torch.zeros(N, mb4p, dtype=self.adt, device=dev); pad[:, :mb4].copy_(db16); db16 = pad
         self._gemm_tn(db16, head["feat16"], self.grad("localization_head.weight"), N, mb4p, self.feat, n_store=mb4, dbias=self.grad("localization_head.bias"))
         wT = self._w16["localization_head.weight.T"]                   # [feat, mb4]
         if mb4p != mb4:
-            wTp = torch.zeros(self.feat, mb4p, dtype=torch.bfloat16, device=dev); wTp[:, :mb4].copy_(wT); wT = wTp
+            wTp = torch.zeros(self.feat, mb4p, dtype=self.adt, device=dev); wTp[:, :mb4].copy_(wT); wT = wTp
         dfeat2 = torch.empty(N, self.feat, device=dev)
         self._gemm_nt(db16, wT, dfeat2, N, self.feat, mb4p, L.EPI_RESID, resid=dfeat)
         # ---- trunk
@@ -484,7 +498,7 @@ class OCRModel:
         import torch
         M, dev = k["y"].shape[0], self.device
         dz = torch.empty(M, c.cout, device=dev)
-        dy = torch.empty(M, c.cout, dtype=torch.bfloat16, device=dev)
+        dy = torch.empty(M, c.cout, dtype=self.adt, device=dev)
         scratch = torch.empty(self.lib.kzv_ocr_bn_scratch_floats(M, c.cout), device=dev)
         L.check(self.lib.kzv_ocr_bn_bwd(da.data_ptr(), k["out"].data_ptr(), k["y"].data_ptr(), M, c.cout, k["mean"].data_ptr(), k["rstd"].data_ptr(),
                                         self.param(c.bn_key + ".weight").data_ptr(), dz.data_ptr(), self.grad(c.bn_key + ".weight").data_ptr(),
@@ -494,7 +508,7 @@ class OCRModel:
 
     def _to16(self, x32):
         import torch
-        out = torch.empty(x32.shape, dtype=torch.bfloat16, device=self.device)
+        out = torch.empty(x32.shape, dtype=self.adt, device=self.device)
         L.check(self.lib.kzv_ocr_cast_bf16(x32.data_ptr(), out.data_ptr(), x32.numel(), L.stream_handle()), "cast")
         return out
 

@@ -20,20 +20,27 @@ class _Act(nn.Module):
     sign of ~0.5 % of the pre-activations that sit next to zero, and each flipped mask element is a 100 % local error of the
     gradient: with the masks replayed, what remains is the rounding of the GEMM operands."""
 
-    def __init__(self, masks):
+    def __init__(self, masks, record=None):
         super().__init__()
         self.masks = masks
+        self.record = record if record is not None else {}          # {"seen": list} -> the masks THIS forward applies, in call order
 
     def forward(self, x):
+        seen = self.record.get("seen")
         if self.masks:
-            return x * self.masks.pop(0).to(x.dtype)
+            mk = self.masks.pop(0)
+            if seen is not None:
+                seen.append(mk.bool())
+            return x * mk.to(x.dtype)
+        if seen is not None:
+            seen.append(x > 0)
         return F.relu(x)
 
 
 class BasicBlock(nn.Module):
-    def __init__(self, cin, cout, stride, masks=None):
+    def __init__(self, cin, cout, stride, masks=None, record=None):
         super().__init__()
-        self.act = _Act(masks if masks is not None else [])
+        self.act = _Act(masks if masks is not None else [], record)
         self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(cout)
         self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
@@ -56,12 +63,13 @@ class OCROracle(nn.Module):
         super().__init__()
         widths = tuple(widths[:len(blocks)])
         self.relu_masks = []            # mask replay: see _Act
-        layers = [nn.Conv2d(3, widths[0], 7, 2, 3, bias=False), nn.BatchNorm2d(widths[0]), _Act(self.relu_masks), nn.MaxPool2d(3, 2, 1)]
+        self.relu_record = {}           # set ["seen"] = [] to collect the masks a forward applies
+        layers = [nn.Conv2d(3, widths[0], 7, 2, 3, bias=False), nn.BatchNorm2d(widths[0]), _Act(self.relu_masks, self.relu_record), nn.MaxPool2d(3, 2, 1)]
         cin = widths[0]
         for si, (nb, wd) in enumerate(zip(blocks, widths)):
             stage = []
             for bi in range(nb):
-                stage.append(BasicBlock(cin, wd, 2 if (bi == 0 and si > 0) else 1, self.relu_masks))
+                stage.append(BasicBlock(cin, wd, 2 if (bi == 0 and si > 0) else 1, self.relu_masks, self.relu_record))
                 cin = wd
             layers.append(nn.Sequential(*stage))
         self.feature_extractor = nn.Sequential(*layers)

@@ -31,6 +31,14 @@ def lib():
     return L.load()
 
 
+@pytest.fixture(autouse=True)
+def _bf16_operands_for_the_per_op_tests():
+    """kzv_ocr_set_precision is process-wide (kzv.OCRModel sets it before each of its passes): the per-operator tests below pass bf16
+    buffers, so each test starts from the bf16 setting whatever model ran before it."""
+    L.check(L.load().kzv_ocr_set_precision(0), "ocr_set_precision")
+    yield
+
+
 def _st():
     return torch.cuda.current_stream().cuda_stream
 
@@ -96,6 +104,154 @@ def test_ctc_whole_page_labels_against_a_length_one_sequence(lib):
     assert float(nll[0]) == 0.0 and float(nll[3]) == 0.0
     assert torch.all(g[:, 0] == 0) and torch.all(g[:, 3] == 0)
     assert (g.cpu() - logits.grad).abs().max() < 2e-5 * max(1.0, logits.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------- fp32 arithmetic (the reference's)
+@pytest.mark.parametrize("M,N,K,nv,resid", [(100, 64, 64, 64, False), (517, 132, 192, 130, True), (16, 1024, 512, 1024, False),
+                                            (512, 512, 4608, 512, True), (8200, 64, 576, 64, False)])
+def test_gemm_nt_f32_matches_fp64(lib, M, N, K, nv, resid):
+    """kzv_gemm_nt_f32 (f32-input MFMA: exact fp32 products, fp32 accumulation) against fp64 products of the same operands: ragged M,
+    n_valid < N (zeroed columns), bias, RESID, shapes that split the reduction over workgroups (few tiles) and shapes that do not."""
+    torch.manual_seed(M + K)
+    A, B = torch.randn(M, K, device=DEV), torch.randn(nv, K, device=DEV) * 0.1
+    bias, res = torch.randn(nv, device=DEV), torch.randn(M, N, device=DEV)
+    out = torch.full((M, N), 7.0, device=DEV)
+    a = L.kzv_gemm_nt_args(A=A.data_ptr(), lda=K, B=B.data_ptr(), ldb=K, C=out.data_ptr(), ldc=N, bias=bias.data_ptr(), resid=res.data_ptr() if resid else None,
+                           ldr=N, aux=None, ldaux=0, M=M, N=N, K=K, n_valid=nv, drop_p=0.0, drop_key=0)
+    L.check(lib.kzv_gemm_nt_f32(C.byref(a), L.EPI_RESID if resid else L.EPI_F32, _st()), "gemm_nt_f32")
+    want = A.double() @ B.double().t() + bias.double()
+    got = out.double()
+    if resid:
+        want = want + res[:, :nv].double()
+        assert torch.equal(out[:, nv:], res[:, nv:])                   # padded columns: 0 + residual
+    else:
+        assert torch.all(out[:, nv:] == 0)
+    scale = want.abs().max().item()
+    assert (got[:, :nv] - want).abs().max().item() < 3e-6 * scale, (got[:, :nv] - want).abs().max().item() / scale      # fp32 accumulation order only
+    first = out.clone()
+    L.check(lib.kzv_gemm_nt_f32(C.byref(a), L.EPI_RESID if resid else L.EPI_F32, _st()), "gemm_nt_f32")
+    assert torch.equal(out, first)                                     # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("Mt,N,K,ns", [(16, 1024, 512, 1024), (131, 64, 192, 64), (8200, 64, 576, 64), (512, 512, 4608, 512), (33, 192, 512, 150)])
+def test_gemm_tn_f32_matches_fp64(lib, Mt, N, K, ns):
+    torch.manual_seed(Mt + N)
+    P, Q = torch.randn(Mt, N, device=DEV), torch.randn(Mt, K, device=DEV)
+    init = torch.randn(ns, K, device=DEV)
+    O, db = init.clone(), torch.ones(ns, device=DEV)
+    a = L.kzv_gemm_tn_args(P=P.data_ptr(), ldp=N, Q=Q.data_ptr(), ldq=K, OUT=O.data_ptr(), ldo=K, Mtok=Mt, N=N, K=K, n_store=ns, dbias=db.data_ptr())
+    L.check(lib.kzv_gemm_tn_f32(C.byref(a), _st()), "gemm_tn_f32")
+    want = init.double() + (P[:, :ns].double().t() @ Q.double())
+    assert (O.double() - want).abs().max().item() < 3e-6 * want.abs().max().item()
+    wb = 1.0 + P[:, :ns].double().sum(0)
+    assert (db.double() - wb).abs().max().item() < 3e-6 * max(1.0, wb.abs().max().item())
+
+
+def test_fp32_model_singles_equal_batched_and_outputs_match_the_oracle_at_full_depth():
+    """ocr_lightning/tests/test_model.py:48-76 at the reference's own precision: OCRModel(precision="fp32") at full ResNet34 depth in
+    eval mode -- singles == batched within 1e-5 of the output scale (the reference asserts atol 1e-6 on outputs of order 0.1; a
+    row's result does not depend on the batch here either, what remains is the split of a short reduction over workgroups) and the
+    outputs within 1e-4 of the fp32 oracle (36 convolutions deep; bf16 operands gave 5e-2)."""
+    c2i, i2c = _vocab()
+    m = OCRModel(c2i, i2c, learning_rate=1e-4, max_boxes=10, init_seed=1, precision="fp32").eval()
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 64, 128)
+    out = m(x)
+    a, b = m(x[:1]), m(x[1:])
+    for k in ("pred_boxes", "pred_logits"):
+        scale = max(1.0, out[k].abs().max().item())
+        assert (out[k][0] - a[k][0]).abs().max().item() < 1e-5 * scale and (out[k][1] - b[k][0]).abs().max().item() < 1e-5 * scale, k
+    o = OCROracle(len(c2i), 0, max_boxes=10)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, strict=True)
+    with torch.no_grad():
+        ref = o.eval()(x)
+    for k in ("pred_boxes", "pred_logits"):
+        assert (out[k].cpu() - ref[k]).abs().max().item() < 1e-4 * max(1.0, ref[k].abs().max().item()), k
+
+
+def _fp32_step_against_float64(blocks, widths, exact_masks):
+    """One training step of OCRModel(precision="fp32") and of the oracle in fp32 and in float64 (the exact value for these weights).
+    Returns per parameter (engine error, torch-fp32 error) against float64 as relative L2 norms, the number of ReLU outputs whose
+    sign differs between the engine and the float64 oracle, and the losses.  exact_masks: the float64 oracle replays the ENGINE's
+    ReLU masks (tests/_replay-style), so that a pre-activation within rounding of zero is not a 100 % local difference."""
+    c2i, i2c = _vocab()
+    mb = 6
+    m = OCRModel(c2i, i2c, learning_rate=1e-3, max_boxes=mb, init_seed=2, precision="fp32", blocks=blocks, widths=widths)
+    sd0 = {k: v.cpu() for k, v in m.state_dict().items()}
+    batch = _batch(6, 64, 160, mb, seed=4)
+    m.train(); m.zero_grad()
+    got = m.training_step(batch, 0)
+    masks = m.relu_masks_of_last_step()
+    m.backward()
+    torch.cuda.synchronize()
+
+    def oracle(dtype, replay):
+        o = OCROracle(len(c2i), 0, max_boxes=mb, blocks=blocks, widths=widths)
+        o.load_state_dict(sd0, strict=True)
+        o = o.to(dtype).train()
+        o.relu_record["seen"] = []
+        if replay:
+            o.relu_masks.extend(masks)
+        b = dict(batch, images=batch["images"].to(dtype), bounding_boxes_batch=batch["bounding_boxes_batch"].to(dtype))
+        total, loc, rec = o.shared_step(b, c2i)
+        total.backward()
+        return o, float(total.detach())
+    o32, t32 = oracle(torch.float32, False)
+    o64, t64 = oracle(torch.float64, False)
+    flips = sum(int((a != b).sum()) for a, b in zip(masks, o64.relu_record["seen"]))
+    elems = sum(a.numel() for a in masks)
+    if exact_masks:
+        o64, t64 = oracle(torch.float64, True)
+    g64 = dict(o64.named_parameters())
+    errs = {}
+    for name, p in o32.named_parameters():
+        g = m.grad(name).cpu()
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        if "weight_hh" in name:
+            assert g.abs().max().item() == 0 and want.abs().max().item() == 0
+            continue
+        exact = g64[name].grad
+        errs[name] = (float((g.double() - exact).norm() / (exact.norm() + 1e-300)), float((want.double() - exact).norm() / (exact.norm() + 1e-300)),
+                      float((g - want).norm() / (want.norm() + 1e-30)), (g - want).abs().max().item() / max(want.abs().max().item(), 1e-30))
+    run = {k: (m.buffers[k].cpu(), v) for k, v in o32.state_dict().items() if "running" in k}
+    return errs, flips, elems, (got, t32, t64), run
+
+
+def test_fp32_training_step_is_as_exact_as_torch_fp32_on_a_four_stage_trunk():
+    """All four stage shapes (64 .. 512 channels, the strided 1x1 shortcuts, reductions of 576 .. 4608 split over workgroups) on a
+    (1, 1, 1, 1) trunk: measured against the oracle in float64, EVERY gradient of the fp32 engine is within 3 x the error torch's own
+    fp32 arithmetic makes (observed 1e-6 .. 3e-6 on both sides).  The reference trains this model in fp32
+    (ocr_lightning/train.py:132-140): this is its arithmetic, not the bf16-operand approximation of round 3."""
+    errs, flips, elems, (got, t32, t64), run = _fp32_step_against_float64((1, 1, 1, 1), (64, 128, 256, 512), exact_masks=False)
+    assert abs(got - t64) < 1e-5 * max(1.0, t64)
+    assert flips == 0, f"{flips} of {elems} ReLU signs differ from float64"
+    worst = max(errs.items(), key=lambda e: e[1][0] / max(e[1][1], 1e-9))
+    for name, (e_engine, e_torch, _, _) in errs.items():
+        assert e_engine < 3.0 * e_torch + 2e-6, (name, e_engine, e_torch)
+    print("fp32 (1,1,1,1): worst engine / torch-fp32 error against float64:", worst[0], worst[1][:2])
+
+
+def test_fp32_full_depth_training_step_matches_the_oracle_without_mask_replay():
+    """The whole training step of the FULL ResNet34 trunk (3, 4, 6, 3) in train mode against oracle/ocr_oracle.py -- the comparison
+    round 3 could only make on a 2-block trunk and by direction.
+    (1) Nothing replayed: losses within 1e-4, every parameter gradient within 1 % of torch's fp32 result in relative L2 norm (and
+        5 % of its largest entry: one flipped ReLU below moves single weight-gradient entries by ~2 %), running statistics within 1e-4.
+    (2) Among the ~3.5 million ReLU outputs of this step a handful of pre-activations sit within fp32 rounding of zero, and whichever
+        way an implementation rounds them is a 100 % local difference of the gradient (observed: 1 - 3 of them, 0.4 % of a
+        gradient's norm); any two fp32 implementations differ there.  So: at most 1e-5 of the ReLU signs may differ from the float64
+        oracle's, and with the engine's masks replayed through the float64 oracle every gradient is within 3 x torch-fp32's own
+        error + 1e-5 of the exact value."""
+    errs, flips, elems, (got, t32, t64), run = _fp32_step_against_float64((3, 4, 6, 3), (64, 128, 256, 512), exact_masks=True)
+    assert abs(got - t32) < 1e-4 * max(1.0, t32)
+    assert flips <= 1e-5 * elems, f"{flips} of {elems} ReLU signs differ from float64"
+    worst = ("", 0.0)
+    for name, (e_engine, e_torch, rel32, max32) in errs.items():
+        assert rel32 < 1e-2 and max32 < 5e-2, (name, rel32, max32)
+        worst = max(worst, (name, e_engine), key=lambda e: e[1])
+        assert e_engine < 3.0 * e_torch + 1e-5, (name, e_engine, e_torch)
+    print(f"fp32 full depth: {flips} of {elems} ReLU signs differ from float64; worst engine error against float64 with the masks replayed", worst)
+    for k, (a, v) in run.items():
+        assert (a - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item()), k
 
 
 # ------------------------------------------------------------------------------------------------- LSTM cell / SmoothL1 / Adam
@@ -288,7 +444,7 @@ def _vocab():
 def test_model_forward_shapes_batch_consistency_and_hparams():
     """ocr_lightning/tests/test_model.py:28-86 against kzv.OCRModel at full ResNet34 depth (eval mode: running statistics)."""
     c2i, i2c = _vocab()
-    m = OCRModel(c2i, i2c, learning_rate=1e-4, max_boxes=10, init_seed=1).eval()
+    m = OCRModel(c2i, i2c, learning_rate=1e-4, max_boxes=10, init_seed=1, precision="bf16").eval()
     torch.manual_seed(0)
     x = torch.randn(2, 3, 64, 128)
     out = m(x)
@@ -337,7 +493,7 @@ def test_two_block_trunk_forward_loss_backward_and_adam_step_match_the_oracle():
     remains is GEMM-operand rounding, and every tensor must agree within 5 % of its largest entry."""
     c2i, i2c = _vocab()
     mb = 4
-    m = OCRModel(c2i, i2c, learning_rate=1e-3, max_boxes=mb, blocks=(1, 1), widths=(64, 128), init_seed=3)
+    m = OCRModel(c2i, i2c, learning_rate=1e-3, max_boxes=mb, blocks=(1, 1), widths=(64, 128), init_seed=3, precision="bf16")
     o = OCROracle(len(c2i), 0, max_boxes=mb, blocks=(1, 1), widths=(64, 128))
     sd0 = {k: v.cpu() for k, v in m.state_dict().items()}
     o.load_state_dict(sd0, strict=True)
