@@ -407,6 +407,10 @@ int kzv_ocr_smooth_l1_boxes(const float* pred, int max_boxes, const float* gt, i
                             float* d_dpred, void* stream);
 /* torch.optim.Adam (model.py:197; no weight decay, no amsgrad), `step` = 1-based step count */
 int kzv_ocr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step, void* stream);
+/* The same step with the bias corrections in device memory: d_bc[0] = 1 - beta1^t, d_bc[1] = sqrt(1 - beta2^t) (fp32).  For a step
+ * replayed from a captured hipGraph (kzv.OCRModel.fit_step): no step-dependent scalar among the kernel arguments. */
+int kzv_ocr_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, const float* d_bc,
+                     void* stream);
 int kzv_ocr_cast_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
 int kzv_ocr_cast_transpose(const float* x, void* out_bf16, int rows, int cols, void* stream);   /* [rows, cols] fp32 -> bf16 [cols, rows] */
 

@@ -152,7 +152,7 @@ __global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gp, float* __
 // ---------------------------------------------------------------------------------------------- BatchNorm2d
 // per-channel sums over the rows of y fp32 [M, C]: pass 0 -> sum(y), pass 1 -> sum((y - mean)^2) with mean = sum0 / M.
 // One thread per (row slice, 4 channels); a block's partials meet through LDS and go to row blockIdx.x of `out` [blocks, C];
-// bn_partial_sum_kernel adds the rows in order (bit-reproducible statistics).
+// bn_rows_reduce_kernel adds the rows in a fixed order (bit-reproducible statistics).
 __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict__ y, int64_t M, int C, const float* __restrict__ sum0,
                                                         float* __restrict__ out, int centered, int rows_per_block) {
     __shared__ float red[256 * 4];
@@ -180,13 +180,34 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const float* __restrict_
         __syncthreads();
     }
 }
-// tot[c] = sum over the `rows` partial rows of part [rows, C], in row order
-__global__ void bn_partial_sum_kernel(const float* __restrict__ part, float* __restrict__ tot, int rows, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += part[(int64_t)r * C + c];
-    tot[c] = s;
+// tot[c] = sum over the `rows` partial rows of part [rows, C] in a FIXED order: 16 channels per workgroup, 16 row slices per channel
+// (slice k adds rows k, k + 16, ... in order; thread 0 of the channel adds the 16 slice sums in order).  FINAL: `part` holds the
+// centred squares, `sum0` the plain sums: mean / rstd and the running statistics come out of the same launch (nn.BatchNorm2d:
+// momentum 0.1, UNBIASED variance into running_var).
+template <bool FINAL>
+__global__ __launch_bounds__(256) void bn_rows_reduce_kernel(const float* __restrict__ part, float* __restrict__ tot, int rows, int C,
+                                                             const float* __restrict__ sum0, float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var, int64_t M, float eps, float momentum) {
+    __shared__ float red[16][17];
+    const int ch = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + ch;
+    float sacc = 0.f;
+    if (c < C) for (int r = slice; r < rows; r += 16) sacc += part[(int64_t)r * C + c];
+    red[slice][ch] = sacc;
+    __syncthreads();
+    if (slice != 0 || c >= C) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][ch];
+    if constexpr (!FINAL) tot[c] = t;
+    else {
+        const float mu = sum0[c] / (float)M, var = t / (float)M;
+        mean[c] = mu; rstd[c] = rsqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mu;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)M / (float)max((int64_t)1, M - 1));
+        }
+    }
 }
 // mean / rstd from the two sums (train) or from the running statistics (eval); train also updates the running statistics the
 // way nn.BatchNorm2d does (momentum 0.1, UNBIASED variance into running_var)
@@ -256,13 +277,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         *(f32x4*)(dbeta + (int64_t)blockIdx.x * C + c) = sb;
     }
 }
-// totals of this launch (read by the second pass) and their accumulation into the gradient buffers
-__global__ void bn_bwd_totals_kernel(const float* __restrict__ pg, const float* __restrict__ pb, float* __restrict__ tot, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int rows, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// totals of this launch (read by the second pass) and their accumulation into the gradient buffers; fixed summation order
+// (bn_rows_reduce_kernel's decomposition)
+__global__ __launch_bounds__(256) void bn_bwd_totals_kernel(const float* __restrict__ pg, const float* __restrict__ pb, float* __restrict__ tot,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C) {
+    __shared__ float red[2][16][17];
+    const int ch = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + ch;
     float g = 0.f, b = 0.f;
-    for (int r = 0; r < rows; ++r) { g += pg[(int64_t)r * C + c]; b += pb[(int64_t)r * C + c]; }
+    if (c < C) for (int r = slice; r < rows; r += 16) { g += pg[(int64_t)r * C + c]; b += pb[(int64_t)r * C + c]; }
+    red[0][slice][ch] = g; red[1][slice][ch] = b;
+    __syncthreads();
+    if (slice != 0 || c >= C) return;
+    g = 0.f; b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { g += red[0][k][ch]; b += red[1][k][ch]; }
     tot[c] = g; tot[C + c] = b;
     dgamma[c] += g; dbeta[c] += b;
 }
@@ -521,6 +550,19 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     m[t] = mm; v[t] = vv;
     p[t] -= (lr / bc1) * mm / (sqrtf(vv) / sqrt_bc2 + eps);
 }
+// the same update with the step's bias corrections read from device memory (bc[0] = 1 - beta1^t, bc[1] = sqrt(1 - beta2^t)): a step
+// replayed from a captured graph has no step-dependent kernel argument
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                float b1, float b2, float eps, const float* __restrict__ bc) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float bc1 = bc[0], sqrt_bc2 = bc[1];
+    const float gr = g[t];
+    const float mm = b1 * m[t] + (1.f - b1) * gr;
+    const float vv = b2 * v[t] + (1.f - b2) * gr * gr;
+    m[t] = mm; v[t] = vv;
+    p[t] -= (lr / bc1) * mm / (sqrtf(vv) / sqrt_bc2 + eps);
+}
 template <bool F32>
 __global__ void cast_bf16_kernel(const float* __restrict__ x, void* __restrict__ out, int64_t n) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,7 +616,9 @@ extern "C" int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, in
     return kzv_check_launch("ocr_conv_wgrad_unpack");
 }
 // d_scratch: kzv_ocr_bn_scratch_floats(M, C) floats
-extern "C" int64_t kzv_ocr_bn_scratch_floats(int64_t M, int C) { return (2 * (int64_t)nblk(M, 256) + 2) * C; }
+// rows per workgroup of the BatchNorm reductions: ~512 workgroups per launch (two rounds of the chip) between 32 and 256 rows each
+static inline int bn_rpb(int64_t M) { const int64_t r = (M + 511) / 512; return r < 32 ? 32 : (r > 256 ? 256 : (int)r); }
+extern "C" int64_t kzv_ocr_bn_scratch_floats(int64_t M, int C) { return (2 * (int64_t)nblk(M, bn_rpb(M)) + 2) * C; }
 extern "C" int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gamma, const float* beta, float* run_mean, float* run_var,
                               float* mean, float* rstd, const void* resid_bf16, void* out_bf16, int relu, int train, float eps, float momentum,
                               float* d_scratch, void* stream) {
@@ -583,14 +627,14 @@ extern "C" int kzv_ocr_bn_fwd(const float* y, int64_t M, int C, const float* gam
     hipStream_t s = (hipStream_t)stream;
     if (train) {
         KZV_OCR_NULL(!d_scratch, "ocr_bn_fwd: scratch");
-        const int rpb = 256, nb = (int)nblk(M, rpb);
+        const int rpb = bn_rpb(M), nb = (int)nblk(M, rpb);
         float* part = d_scratch + 2 * C;                       // [nb, C] partial rows, reused by both passes
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(nb), dim3(256), 0, s, y, M, C, nullptr, part, 0, rpb);
-        hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, part, d_scratch, nb, C);
+        hipLaunchKernelGGL(bn_rows_reduce_kernel<false>, dim3(nblk(C, 16)), dim3(256), 0, s, part, d_scratch, nb, C, nullptr, nullptr, nullptr, nullptr, nullptr, M, eps, momentum);
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(nb), dim3(256), 0, s, y, M, C, d_scratch, part, 1, rpb);
-        hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, part, d_scratch + C, nb, C);
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, d_scratch, d_scratch ? d_scratch + C : nullptr, mean, rstd, run_mean, run_var, C, M, eps, momentum, train);
+        hipLaunchKernelGGL(bn_rows_reduce_kernel<true>, dim3(nblk(C, 16)), dim3(256), 0, s, part, d_scratch + C, nb, C, d_scratch, mean, rstd, run_mean, run_var, M, eps, momentum);
+    } else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, nullptr, nullptr, mean, rstd, run_mean, run_var, C, M, eps, momentum, 0);
     KZV_OCR_LAUNCH(bn_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), s, y, mean, rstd, gamma, beta, resid_bf16, out_bf16, M, C, relu);
     return kzv_check_launch("ocr_bn_fwd");
 }
@@ -599,11 +643,11 @@ extern "C" int kzv_ocr_bn_bwd(const float* da, const void* a_bf16, const float* 
                               void* stream) {
     KZV_OCR_NULL(!da || !y || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || !dy_bf16 || !d_scratch || (relu && !a_bf16) || C % 4 || C > 1024, "ocr_bn_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = 256, nb = (int)nblk(M, rpb);
+    const int rpb = bn_rpb(M), nb = (int)nblk(M, rpb);
     float* tot = d_scratch;                                    // [2, C]: this launch's dgamma | dbeta (the second pass needs them complete)
     float* pg = d_scratch + 2 * C; float* pb = pg + (int64_t)nb * C;
     KZV_OCR_LAUNCH(bn_bwd_reduce_kernel, dim3(nb), dim3(256), s, da, a_bf16, y, mean, rstd, dz, pg, pb, M, C, relu, rpb);
-    hipLaunchKernelGGL(bn_bwd_totals_kernel, dim3(nblk(C, 256)), dim3(256), 0, s, pg, pb, tot, dgamma, dbeta, nb, C);
+    hipLaunchKernelGGL(bn_bwd_totals_kernel, dim3(nblk(C, 16)), dim3(256), 0, s, pg, pb, tot, dgamma, dbeta, nb, C);
     KZV_OCR_LAUNCH(bn_bwd_apply_kernel, dim3(nblk(M * (C / 4), 256)), dim3(256), s, dz, y, mean, rstd, gamma, tot, tot + C, dy_bf16, M, C, train);
     return kzv_check_launch("ocr_bn_bwd");
 }
@@ -672,6 +716,11 @@ extern "C" int kzv_ocr_adam(float* p, const float* g, float* m, float* v, int64_
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
     return kzv_check_launch("ocr_adam");
+}
+extern "C" int kzv_ocr_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, const float* d_bc, void* stream) {
+    KZV_OCR_NULL(!p || !g || !m || !v || n <= 0 || !d_bc, "ocr_adam_dev: bad argument");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, d_bc);
+    return kzv_check_launch("ocr_adam_dev");
 }
 extern "C" int kzv_ocr_cast_bf16(const float* x, void* out, int64_t n, void* stream) {
     KZV_OCR_NULL(!x || !out || n <= 0, "ocr_cast_bf16: bad argument");

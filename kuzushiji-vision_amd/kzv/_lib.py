@@ -155,6 +155,7 @@ SYMBOLS = {
     "kzv_ocr_ctc": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "kzv_ocr_smooth_l1_boxes": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P]),
     "kzv_ocr_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+    "kzv_ocr_adam_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "kzv_ocr_cast_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "kzv_ocr_cast_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "kzv_prof_enable": (C.c_int, [C.c_int, C.c_int]),

@@ -71,6 +71,7 @@ class OCRModel:
         self.logged: dict[str, list[float]] = {}
         self._optimizer = None
         self._step = 0
+        self._graphs = {}
         # ---- parameter table in the reference's registration order ------------------------------------------------
         self.convs: list[_Conv] = []
         shapes: list[tuple[str, tuple[int, ...]]] = []
@@ -358,56 +359,86 @@ class OCRModel:
         return b
 
     # ------------------------------------------------------------------------------------------------ loss + backward
-    def _shared_step(self, batch, batch_idx, step_name):
-        """model.py:90-195: SmoothL1 over each sample's first min(count, max_boxes) boxes (mean over the samples that have any) +
-        CTC (blank, zero_infinity, 'mean') over the samples with a non-empty label, on the length-1 log-probabilities."""
+    CTC_LD = 32          # target columns handed to the CTC kernel: only labels of <= 1 character align with the length-1 sequence,
+                         # longer ones are infeasible whatever they spell (loss 0, no gradient) -- their first characters are enough
+
+    def _host_labels(self, label_texts):
+        """Labels encoded like model.py:135-139 (unknown characters -> blank): the host half of the recognition loss."""
+        hp = self.hparams
+        enc = [[hp.char_to_idx.get(ch, hp.blank_char_idx) for ch in text] for text in label_texts]
+        lens = [len(e) for e in enc]
+        nvalid = sum(1 for n in lens if n > 0)
+        return SimpleNamespace(enc=enc, lens=lens, nvalid=nvalid, Lmax=max(lens) if lens else 0,
+                               gs=[self.rec_loss_weight / (max(n, 1) * nvalid) if n > 0 else 0.0 for n in lens])
+
+    def _label_tensors(self, lab, B, into=None):
+        """Device inputs of the CTC launch (into: the static buffers of a captured step, refilled in place)."""
+        import torch
+        hp, dev = self.hparams, self.device
+        tg = torch.full((B, self.CTC_LD), hp.blank_char_idx, dtype=torch.int64)
+        for i, e in enumerate(lab.enc):
+            k = min(len(e), self.CTC_LD)
+            tg[i, :k] = torch.tensor(e[:k], dtype=torch.int64)
+        tl = torch.tensor(lab.lens, dtype=torch.int64)
+        gs = torch.tensor(lab.gs, dtype=torch.float32)
+        if into is None:
+            return SimpleNamespace(tg=tg.to(dev), tl=tl.to(dev), il=torch.ones(B, dtype=torch.int64, device=dev), gs=gs.to(dev))
+        into.tg.copy_(tg, non_blocking=True); into.tl.copy_(tl, non_blocking=True); into.gs.copy_(gs, non_blocking=True)
+        return into
+
+    def _loss_launch(self, head, gt, counts, lt, has_ctc):
+        """The device half of model.py:90-195 (launches only, no host read: capturable): SmoothL1 over each sample's first
+        min(count, max_boxes) boxes (mean over the samples that have any) + CTC (blank, zero_infinity, 'mean') over the samples with a
+        non-empty label, on the length-1 log-probabilities.  Returns device tensors (loc [1], nll [B], dboxes, dlogits)."""
         import torch
         lib, st, dev, hp = self.lib, L.stream_handle(), self.device, self.hparams
-        images, label_texts = batch["images"], batch["label_texts"]
-        gt = batch["bounding_boxes_batch"].to(dev, torch.float32).contiguous()
-        counts = torch.as_tensor(batch["bbox_counts"], dtype=torch.int32).to(dev)
-        B = images.shape[0]
-        tape = []
-        out = self.forward(images, _tape=tape)
-        head = tape[-1][1]
         boxes, logits = head["boxes"], head["logits"]
-        # ---- localisation
+        B = boxes.shape[0]
         loc = torch.zeros(1, device=dev)
         dboxes = torch.empty(B, hp.max_boxes * 4, device=dev)
         gtb = gt.shape[1] if gt.dim() == 3 else 0
         L.check(lib.kzv_ocr_smooth_l1_boxes(boxes.data_ptr(), hp.max_boxes, gt.data_ptr() if gtb else None, gtb, counts.data_ptr(), B, loc.data_ptr(),
                                             dboxes.data_ptr(), st), "smooth_l1")
-        # ---- recognition: labels encoded like model.py:135-139 (unknown characters -> blank)
-        enc = [[hp.char_to_idx.get(ch, hp.blank_char_idx) for ch in text] for text in label_texts]
-        lens = [len(e) for e in enc]
-        Lmax = max(lens) if lens else 0
-        nvalid = sum(1 for n in lens if n > 0)
         nc = hp.num_chars
         dlogits = torch.zeros(B, self.Cp, device=dev)
-        rec_val = 0.0
         nll = torch.zeros(B, device=dev)
-        if nvalid > 0 and Lmax > 0:
-            tg = torch.full((B, Lmax), hp.blank_char_idx, dtype=torch.int64)
-            for i, e in enumerate(enc):
-                tg[i, :len(e)] = torch.tensor(e, dtype=torch.int64)
-            tg = tg.to(dev)
-            tl = torch.tensor(lens, dtype=torch.int64, device=dev)
-            il = torch.ones(B, dtype=torch.int64, device=dev)
-            gs = torch.tensor([self.rec_loss_weight / (max(n, 1) * nvalid) if n > 0 else 0.0 for n in lens], dtype=torch.float32, device=dev)
+        if has_ctc:
             lp = torch.empty(B, nc, device=dev)
             lg = logits[:, :nc].contiguous()
             L.check(lib.kzv_ocr_log_softmax(lg.data_ptr(), lp.data_ptr(), B, nc, st), "log_softmax")
-            S = 2 * min(Lmax, 1) + 1                   # states of the labels that fit the length-1 sequence (longer ones: loss 0, no gradient)
-            scratch = torch.empty(2 * B * S, device=dev)
+            scratch = torch.empty(2 * B * 3, device=dev)            # 2 * B * T * (2 * min(L, T) + 1) with T = 1
             dl = torch.empty(B, nc, device=dev)
-            L.check(lib.kzv_ocr_ctc(lp.data_ptr(), tg.data_ptr(), Lmax, il.data_ptr(), tl.data_ptr(), 1, B, nc, hp.blank_char_idx, 1, Lmax,
-                                    scratch.data_ptr(), nll.data_ptr(), gs.data_ptr(), dl.data_ptr(), st), "ctc")
+            L.check(lib.kzv_ocr_ctc(lp.data_ptr(), lt.tg.data_ptr(), self.CTC_LD, lt.il.data_ptr(), lt.tl.data_ptr(), 1, B, nc, hp.blank_char_idx, 1,
+                                    self.CTC_LD, scratch.data_ptr(), nll.data_ptr(), lt.gs.data_ptr(), dl.data_ptr(), st), "ctc")
             dlogits[:, :nc].copy_(dl)
+        return loc, nll, dboxes, dlogits
+
+    def _loss_values(self, loc, nll, lab, step_name):
+        """Host half: the three logged values (one device -> host read each)."""
+        rec_val = 0.0
+        if lab.nvalid > 0 and lab.Lmax > 0:
             nl = nll.cpu()
-            rec_val = float(sum(float(nl[i]) / max(lens[i], 1) for i in range(B) if lens[i] > 0) / nvalid)
+            rec_val = float(sum(float(nl[i]) / max(lab.lens[i], 1) for i in range(len(lab.lens)) if lab.lens[i] > 0) / lab.nvalid)
         loc_val = float(loc.item())
         total = self.loc_loss_weight * loc_val + self.rec_loss_weight * rec_val
         self.log(f"{step_name}/loc_loss", loc_val); self.log(f"{step_name}/rec_loss", rec_val); self.log(f"{step_name}/total_loss", total)
+        return total
+
+    def _shared_step(self, batch, batch_idx, step_name):
+        """model.py:90-195 (see _loss_launch)."""
+        import torch
+        dev = self.device
+        images = batch["images"]
+        gt = batch["bounding_boxes_batch"].to(dev, torch.float32).contiguous()
+        counts = torch.as_tensor(batch["bbox_counts"], dtype=torch.int32).to(dev)
+        B = images.shape[0]
+        tape = []
+        self.forward(images, _tape=tape)
+        lab = self._host_labels(batch["label_texts"])
+        has_ctc = lab.nvalid > 0 and lab.Lmax > 0
+        lt = self._label_tensors(lab, B) if has_ctc else None
+        loc, nll, dboxes, dlogits = self._loss_launch(tape[-1][1], gt, counts, lt, has_ctc)
+        total = self._loss_values(loc, nll, lab, step_name)
         self._pending = (tape, dboxes * self.loc_loss_weight if self.loc_loss_weight != 1.0 else dboxes, dlogits)
         return total
 
@@ -536,24 +567,82 @@ class OCRModel:
                                           lr=self.hparams.learning_rate, betas=(0.9, 0.999), eps=1e-8)
         return self._optimizer
 
-    def optimizer_step(self):
+    def optimizer_step(self, _bc=None):
+        """optim.Adam.step + the refresh of the operand copies.  _bc: a device [2] buffer holding this step's bias corrections
+        (1 - beta1^t, sqrt(1 - beta2^t)) -- the captured step passes one so that no step-dependent scalar is baked into the graph."""
         o = self._optimizer or self.configure_optimizers()
-        o.step_count += 1
-        L.check(self.lib.kzv_ocr_adam(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), o.m.data_ptr(), o.v.data_ptr(), self.total, o.lr,
-                                      o.betas[0], o.betas[1], o.eps, o.step_count, L.stream_handle()), "adam")
+        if _bc is None:
+            o.step_count += 1
+            L.check(self.lib.kzv_ocr_adam(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), o.m.data_ptr(), o.v.data_ptr(), self.total, o.lr,
+                                          o.betas[0], o.betas[1], o.eps, o.step_count, L.stream_handle()), "adam")
+        else:
+            L.check(self.lib.kzv_ocr_adam_dev(self.flat_params.data_ptr(), self.flat_grads.data_ptr(), o.m.data_ptr(), o.v.data_ptr(), self.total, o.lr,
+                                              o.betas[0], o.betas[1], o.eps, _bc.data_ptr(), L.stream_handle()), "adam_dev")
         self.sync_weights()
 
     def fit_step(self, batch, batch_idx=0):
         """One optimisation step the way Lightning drives the reference: zero_grad, training_step, backward, [DDP gradient mean when
         a process group is up: pl.Trainer(devices=N) of ocr_lightning/train.py:132-140 -- one all-reduce of the flat gradient buffer,
-        BatchNorm statistics stay per rank as in plain DDP], Adam."""
+        BatchNorm statistics stay per rank as in plain DDP], Adam.
+
+        Single process: from the third step of a batch geometry on, the ~700 launches of the step are replayed from ONE captured
+        hipGraph (``use_graph``, default on): the eager step is bound by the host issuing its launches from Python, not by the GPU."""
+        import torch.distributed as dist
         self.train()
+        if self.use_graph and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return self._fit_step_graph(batch)
+        return self._fit_step_eager(batch, batch_idx)
+
+    def _fit_step_eager(self, batch, batch_idx=0):
         self.zero_grad()
         loss = self.training_step(batch, batch_idx)
         self.backward()
         self.allreduce_grads()
         self.optimizer_step()
         return loss
+
+    use_graph = True
+    GRAPH_WARM_STEPS = 2          # eager steps of a geometry before it is captured (library workspaces reach their final size)
+
+    def _fit_step_graph(self, batch):
+        import torch
+        dev = self.device
+        images = batch["images"].to(dev, torch.float32).contiguous()
+        gt = batch["bounding_boxes_batch"].to(dev, torch.float32).contiguous()
+        B = images.shape[0]
+        lab = self._host_labels(batch["label_texts"])
+        has_ctc = lab.nvalid > 0 and lab.Lmax > 0
+        key = (tuple(images.shape), tuple(gt.shape), has_ctc)
+        ent = self._graphs.setdefault(key, SimpleNamespace(seen=0, graph=None))
+        ent.seen += 1
+        if ent.graph is None and ent.seen <= self.GRAPH_WARM_STEPS:
+            return self._fit_step_eager(batch)
+        o = self._optimizer or self.configure_optimizers()
+        if ent.graph is None:
+            ent.images, ent.gt = torch.empty_like(images), torch.empty_like(gt)
+            ent.counts = torch.zeros(B, dtype=torch.int32, device=dev)
+            ent.lt = SimpleNamespace(tg=torch.zeros(B, self.CTC_LD, dtype=torch.int64, device=dev), tl=torch.zeros(B, dtype=torch.int64, device=dev),
+                                     il=torch.ones(B, dtype=torch.int64, device=dev), gs=torch.zeros(B, device=dev))
+            ent.bc = torch.ones(2, device=dev)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.zero_grad()
+                tape = []
+                self.forward(ent.images, _tape=tape)
+                ent.loc, ent.nll, dboxes, dlogits = self._loss_launch(tape[-1][1], ent.gt, ent.counts, ent.lt, has_ctc)
+                self._pending = (tape, dboxes * self.loc_loss_weight if self.loc_loss_weight != 1.0 else dboxes, dlogits)
+                self.backward()
+                self.optimizer_step(_bc=ent.bc)
+            ent.graph = g
+        ent.images.copy_(images, non_blocking=True); ent.gt.copy_(gt, non_blocking=True)
+        ent.counts.copy_(torch.as_tensor(batch["bbox_counts"], dtype=torch.int32), non_blocking=True)
+        if has_ctc:
+            self._label_tensors(lab, B, into=ent.lt)
+        o.step_count += 1
+        ent.bc.copy_(torch.tensor([1.0 - o.betas[0] ** o.step_count, math.sqrt(1.0 - o.betas[1] ** o.step_count)], dtype=torch.float32), non_blocking=True)
+        ent.graph.replay()
+        return self._loss_values(ent.loc, ent.nll, lab, "train")
 
     def allreduce_grads(self):
         import torch.distributed as dist

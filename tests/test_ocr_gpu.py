@@ -577,6 +577,29 @@ def test_fit_steps_reduce_the_loss_and_eval_uses_running_statistics():
     assert dec[0] == "a" and dec[2] == "7" and dec[4] == "q" and dec[5] == "b", dec
 
 
+def test_graph_replayed_fit_steps_equal_eager_ones():
+    """fit_step replays the whole optimisation step (zero_grad, forward, losses, backward, Adam, operand refresh: ~200 launches on this
+    trunk) from one captured hipGraph from the third step of a batch geometry on; the batch contents, the label texts and Adam's bias
+    corrections reach it through device buffers.  Same parameters and losses as the launch-by-launch path on a stream of DIFFERENT
+    batches (the box loss sums with float atomics: 1e-6)."""
+    c2i, i2c = _vocab()
+    ms = [OCRModel(c2i, i2c, learning_rate=2e-3, max_boxes=4, blocks=(1, 1), widths=(64, 128), init_seed=5) for _ in range(2)]
+    ms[1].use_graph = False
+    for m in ms:
+        m.configure_optimizers()
+    batches = [_batch(6, 32, 48, 4, seed=20 + i) for i in range(3)]
+    batches[1]["label_texts"] = ["q", "zz", "", "a", "7", "abc" * 100]
+    losses = [[m.fit_step(batches[i % 3], i) for i in range(7)] for m in ms]
+    assert ms[0]._graphs and all(e.graph is not None for e in ms[0]._graphs.values()) and not ms[1]._graphs
+    assert np.allclose(losses[0], losses[1], rtol=1e-5, atol=1e-6), (losses[0], losses[1])
+    for name in ms[0].offsets:
+        a, b = ms[0].param(name), ms[1].param(name)
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), name
+    for k in ms[0].buffers:
+        assert torch.allclose(ms[0].buffers[k].float(), ms[1].buffers[k].float(), rtol=1e-4, atol=1e-5), k      # (7 Adam steps amplify the 1e-7 of the atomics)
+    assert ms[0]._optimizer.step_count == ms[1]._optimizer.step_count == 7
+
+
 def test_training_step_accepts_whole_page_label_texts():
     """A page text of several hundred characters (what ocr_lightning's dataset yields) in the batch: the step runs, the long
     sample contributes rec loss 0 like nn.CTCLoss(zero_infinity=True) against one time step, the short ones still train."""
