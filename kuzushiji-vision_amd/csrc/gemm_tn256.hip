@@ -39,6 +39,12 @@ constexpr int HT_BYTES = 64 * 256;         // half-tile: 64 tokens x 128 bf16
 constexpr int BUF_BYTES = 4 * HT_BYTES;    // P-h0, P-h1, Q-h0, Q-h1
 constexpr int LDS_BYTES = 2 * BUF_BYTES;   // 128 KiB
 constexpr int KP0 = 0, KP1 = 1, KQ0 = 2, KQ1 = 3;
+// floats of workspace per 256 x 256 partial tile: bf16 partials (default) take half a float per element
+#ifndef KZV_TN_F32_PARTIALS
+constexpr size_t PART_FLOATS = 32768;
+#else
+constexpr size_t PART_FLOATS = 65536;
+#endif
 
 __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TnParams p, float
     // (fp32 [128][256], 16-B chunks XOR (row & 31)) -> this workgroup's partial tile in the workspace, one 1-KiB row
     // per wave-instruction, streamed past L2 ----
     float* tile = (float*)smem;
-    float* part = part_ws + (size_t)id * 65536;                       // [256][256] fp32 per workgroup (id = split * per + tile)
+    float* part = part_ws + (size_t)id * PART_FLOATS;                       // [256][256] fp32 per workgroup (id = split * per + tile)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         __syncthreads();                           // the ring / the previous chunk is no longer being read
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm_tn256f_kernel(const TnParams p, floa
 
     // ---- epilogue: as gemm_tn256_kernel ----
     float* tile = (float*)smem;
-    float* part = part_ws + (size_t)id * 65536;
+    float* part = part_ws + (size_t)id * PART_FLOATS;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         __syncthreads();
@@ -493,17 +499,20 @@ __global__ __launch_bounds__(256) void gemm_tn256_fold_kernel(const float* part_
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2p;
 #pragma unroll 4
     for (int sp = 0; sp < splits; ++sp) {
-        const u32x2p u = __builtin_nontemporal_load((const u32x2p*)((const bf16_t*)(part_ws + ((size_t)sp * per + tile) * 65536) + row * 256 + k4));
+        const u32x2p u = __builtin_nontemporal_load((const u32x2p*)((const bf16_t*)(part_ws + ((size_t)sp * per + tile) * PART_FLOATS) + row * 256 + k4));
         s[0] += bf2f((bf16_t)(u[0] & 0xffffu)); s[1] += bf2f((bf16_t)(u[0] >> 16)); s[2] += bf2f((bf16_t)(u[1] & 0xffffu)); s[3] += bf2f((bf16_t)(u[1] >> 16));
     }
 #else
 #pragma unroll 4
-    for (int sp = 0; sp < splits; ++sp) s += __builtin_nontemporal_load((const f32x4*)(src + (size_t)sp * per * 65536));
+    for (int sp = 0; sp < splits; ++sp) s += __builtin_nontemporal_load((const f32x4*)(src + (size_t)sp * per * PART_FLOATS));
 #endif
     f32x4* o = (f32x4*)(OUT + (int64_t)gn * ldo + gk);
     *o += s;
 }
 
+// Invariant of the deferred folds (KzvTnFoldScope, and KzvLnDeferScope in layernorm.hip): the pending lists are process-global and
+// unsynchronised -- ONE host thread issues the launches of a scope, on ONE stream (model.cpp's backward); a scope held open defers
+// every kzv_gemm_tn of the process.  Outputs inside a scope must be distinct (a repeated one is folded first, below).
 // Partial-tile workspace: TN_REGIONS regions of the largest size asked for so far (grow-only; calls are stream-ordered).  Region 0
 // serves a launch whose fold follows at once; regions 1.. the launches of a KzvTnFoldScope (the four weight gradients of an encoder
 // layer), whose folds are ONE launch when the scope closes: a fold is ~5 us of launch latency + ~5 us of data, 49 times per step.
@@ -538,13 +547,13 @@ __global__ __launch_bounds__(256) void gemm_tn256_fold_multi_kernel(const TnFold
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2p;
 #pragma unroll 4
     for (int sp = 0; sp < e.splits; ++sp) {
-        const u32x2p u = __builtin_nontemporal_load((const u32x2p*)((const bf16_t*)(e.ws + ((size_t)sp * e.per + tile) * 65536) + row * 256 + k4));
+        const u32x2p u = __builtin_nontemporal_load((const u32x2p*)((const bf16_t*)(e.ws + ((size_t)sp * e.per + tile) * PART_FLOATS) + row * 256 + k4));
         s[0] += bf2f((bf16_t)(u[0] & 0xffffu)); s[1] += bf2f((bf16_t)(u[0] >> 16)); s[2] += bf2f((bf16_t)(u[1] & 0xffffu)); s[3] += bf2f((bf16_t)(u[1] >> 16));
     }
 #else
     const float* src = e.ws + ((size_t)tile * 256 + row) * 256 + k4;
 #pragma unroll 4
-    for (int sp = 0; sp < e.splits; ++sp) s += __builtin_nontemporal_load((const f32x4*)(src + (size_t)sp * e.per * 65536));
+    for (int sp = 0; sp < e.splits; ++sp) s += __builtin_nontemporal_load((const f32x4*)(src + (size_t)sp * e.per * PART_FLOATS));
 #endif
     f32x4* o = (f32x4*)(e.OUT + (int64_t)gn * e.ldo + gk);
     *o += s;
@@ -606,10 +615,12 @@ int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr_done = true; }
     if (p.K % 4 || p.ldo % 4 || ((uintptr_t)p.OUT & 15)) return 0;
-    const size_t need = (size_t)tiles * splits * 65536;
+    const size_t need = (size_t)tiles * splits * PART_FLOATS;
     const bool deferred = g_tn_defer > 0;
-    if (deferred && ((int)g_tn_pending.size() == TN_REGIONS - 1 || need > g_tn_region)) {
-        if (tn_flush(s) != KZV_OK) return 0;     // no free region, or the workspace is about to be re-allocated: fold what is pending first
+    bool same_out = false;                       // a second gradient into the SAME output inside one scope: the single fold launch adds every
+    for (const TnFold& e : g_tn_pending) same_out |= e.OUT == p.OUT;      // entry with a plain read-modify-write, so the two would race
+    if (deferred && ((int)g_tn_pending.size() == TN_REGIONS - 1 || need > g_tn_region || same_out)) {
+        if (tn_flush(s) != KZV_OK) return 0;     // no free region, the workspace is about to be re-allocated, or a repeated output: fold what is pending first
     }
     float* ws = tn_partials(need, deferred ? 1 + (int)g_tn_pending.size() : 0);
     if (!ws) return 0;

@@ -440,7 +440,9 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     if (!p.partial) return kzv_fail(KZV_E_HIP, "layernorm_bwd: partial-sum buffer unavailable");
     const bool deferred = g_ln_defer > 0;
     if (deferred) {                                  // a region of its own until the scope's fold
-        if ((int)g_ln_pending.size() == LN_REGIONS - 1) KZV_LN_TRY(ln_flush(s));
+        bool same_out = false;                       // the single fold launch adds every entry with a plain `*out += s`: a LayerNorm that
+        for (const LnFold& e : g_ln_pending) same_out |= e.dgamma == dgamma || e.dbeta == dbeta;      // appears twice in a scope is folded first
+        if ((int)g_ln_pending.size() == LN_REGIONS - 1 || same_out) KZV_LN_TRY(ln_flush(s));
         p.partial += (1 + g_ln_pending.size()) * LN_REGION_FLOATS;
     }
     const bool fast = H == ncl * 256 && ncl <= 4;

@@ -32,6 +32,16 @@ def test_header_symbols_are_exported_and_bound(lib):
     assert lib.kzv_version() >= 1
 
 
+def test_kernels_whose_inline_asm_clobbers_m0_hold_no_compiler_generated_m0_use():
+    """The LDS-DMA helpers of the GEMM / attention-backward kernels write M0 from inline asm and leave it clobbered; hipcc cannot be
+    told (m0 is reserved: a clobber entry is ignored), so tools/check_m0.py compiles those sources and scans the gfx950 assembly:
+    no kernel mixes an asm M0 write with a compiler-generated M0 use."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_m0.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("cfg", [tiny_config(), vit_b_config(), vit_b_config(dec_layers=6)])
 def test_param_table_matches_python(lib, cfg):
     from kzv.model import TrOCRModel  # noqa: F401  (import must not need a GPU)
