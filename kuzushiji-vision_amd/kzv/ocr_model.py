@@ -567,6 +567,45 @@ class OCRModel:
                                           lr=self.hparams.learning_rate, betas=(0.9, 0.999), eps=1e-8)
         return self._optimizer
 
+    def optimizer_state_dict(self):
+        """torch.optim.Adam's own ``state_dict()`` layout (what Lightning's ModelCheckpoint stores under ``optimizer_states[0]`` for
+        the reference, ocr_lightning/train.py:118-140): per parameter -- in the reference's registration order -- ``step``,
+        ``exp_avg``, ``exp_avg_sq``; one param group."""
+        import torch
+        o = self._optimizer or self.configure_optimizers()
+        names = list(self.offsets)
+        state = {}
+        if o.step_count > 0:
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(o.step_count)), "exp_avg": self._view(o.m, n).detach().cpu().clone(),
+                            "exp_avg_sq": self._view(o.v, n).detach().cpu().clone()}
+        group = {"lr": o.lr, "betas": tuple(o.betas), "eps": o.eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """The inverse: Adam moments and step count from a checkpoint the reference (or this engine) wrote."""
+        import torch
+        o = self._optimizer or self.configure_optimizers()
+        names = list(self.offsets)
+        g = sd["param_groups"][0]
+        if len(g["params"]) != len(names):
+            raise KeyError(f"optimizer state holds {len(g['params'])} parameters, the model {len(names)}")
+        o.lr, o.betas, o.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
+        self.hparams.learning_rate = o.lr
+        steps = set()
+        o.m.zero_(); o.v.zero_()
+        for i, pid in enumerate(g["params"]):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            self._view(o.m, names[i]).copy_(torch.as_tensor(st["exp_avg"]).to(self.device, torch.float32).reshape(self.offsets[names[i]][1]))
+            self._view(o.v, names[i]).copy_(torch.as_tensor(st["exp_avg_sq"]).to(self.device, torch.float32).reshape(self.offsets[names[i]][1]))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one flat Adam step serves every parameter here")
+        o.step_count = steps.pop() if steps else 0
+
     def optimizer_step(self, _bc=None):
         """optim.Adam.step + the refresh of the operand copies.  _bc: a device [2] buffer holding this step's bias corrections
         (1 - beta1^t, sqrt(1 - beta2^t)) -- the captured step passes one so that no step-dependent scalar is baked into the graph."""

@@ -71,6 +71,9 @@ def parse_args(argv=None):
     p.add_argument("--max_boxes", type=int, default=50)
     p.add_argument("--epochs", type=int, default=10)
     p.add_argument("--patience", type=int, default=3)
+    p.add_argument("--resume", type=str, default=None,
+                   help="--model ocr: continue from a checkpoint this CLI (or Lightning, for the reference) wrote -- weights, Adam moments and "
+                        "step count, epoch (pl.Trainer.fit(ckpt_path=...))")
     return p.parse_args(argv)
 
 
@@ -100,9 +103,18 @@ def main_ocr(args):
     val_loader = OcrLoader(val_ds, args.batch_size) if len(val_ds) else None
     model = OCRModel(CHAR_TO_IDX, IDX_TO_CHAR, learning_rate=args.learning_rate, max_boxes=args.max_boxes, init_seed=args.seed, device=f"cuda:{local}")
     model.configure_optimizers()
+    start_epoch = 0
+    if getattr(args, "resume", None):                       # what pl.Trainer.fit(ckpt_path=...) restores: weights, Adam state, epoch
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["state_dict"], strict=True)
+        if ck.get("optimizer_states"):
+            model.load_optimizer_state_dict(ck["optimizer_states"][0])
+        start_epoch = int(ck.get("epoch", -1)) + 1
+        if rank == 0:
+            print(f"Resumed from {args.resume}: epoch {start_epoch}, optimizer step {model._optimizer.step_count}")
     state, hist = {"best": float("inf"), "best_path": None, "bad": 0}, []
     log = open(os.path.join(args.log_dir, "metrics.jsonl") if rank == 0 else os.devnull, "a", encoding="utf-8")
-    for epoch in range(args.epochs):
+    for epoch in range(start_epoch, args.epochs):
         train_loader.set_epoch(epoch)
         model.logged.clear()
         for i, batch in enumerate(train_loader):
@@ -140,8 +152,10 @@ def _ocr_epoch_end(args, model, rec, epoch, log, state):
     best, best_path, bad = state["best"], state["best_path"], state["bad"]
     log.write(json.dumps(rec) + "\n"); log.flush()
     print(" ".join(f"{k}={v:.4f}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()))
-    torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch},
-               os.path.join(args.checkpoint_dir, "last.ckpt"))
+    def ckpt():      # Lightning's layout for the keys the reference's checkpoints carry (ModelCheckpoint(save_last=True), train.py:118-126)
+        return {"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch,
+                "global_step": model._optimizer.step_count if model._optimizer else 0, "optimizer_states": [model.optimizer_state_dict()], "lr_schedulers": []}
+    torch.save(ckpt(), os.path.join(args.checkpoint_dir, "last.ckpt"))
     vl = rec.get("val/total_loss")
     if vl is not None:
         if vl < best:
@@ -149,7 +163,7 @@ def _ocr_epoch_end(args, model, rec, epoch, log, state):
             if best_path and os.path.exists(best_path):
                 os.remove(best_path)
             best_path = os.path.join(args.checkpoint_dir, f"ocr-epoch={epoch:02d}-val_total_loss={vl:.2f}.ckpt")
-            torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "hyper_parameters": vars(model.hparams), "epoch": epoch}, best_path)
+            torch.save(ckpt(), best_path)
         else:
             bad += 1
             if bad >= args.patience:

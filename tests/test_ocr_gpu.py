@@ -600,6 +600,47 @@ def test_graph_replayed_fit_steps_equal_eager_ones():
     assert ms[0]._optimizer.step_count == ms[1]._optimizer.step_count == 7
 
 
+def test_optimizer_state_round_trips_in_adams_own_layout_and_a_resumed_run_continues_exactly():
+    """the OCR checkpoints carry optim.Adam's state (Lightning's ``optimizer_states[0]``).  (1) The state_dict loads into a
+    torch.optim.Adam over the oracle's parameters (same registration order) and equals what torch computes from the same gradients;
+    (2) a second model that loads weights + optimizer state after 3 steps and takes 2 more ends where the uninterrupted 5-step run ends."""
+    c2i, i2c = _vocab()
+    kw = dict(learning_rate=2e-3, max_boxes=4, blocks=(1, 1), widths=(64, 128), init_seed=5)
+    full, part = OCRModel(c2i, i2c, **kw), OCRModel(c2i, i2c, **kw)
+    for m in (full, part):
+        m.configure_optimizers(); m.use_graph = False
+    batches = [_batch(6, 32, 48, 4, seed=40 + i) for i in range(5)]
+    for i in range(5):
+        full.fit_step(batches[i], i)
+    o = OCROracle(len(c2i), 0, max_boxes=4, blocks=(1, 1), widths=(64, 128))
+    o.load_state_dict({k: v.cpu() for k, v in part.state_dict().items()}, strict=True)
+    opt = torch.optim.Adam(o.parameters(), lr=2e-3)
+    for i in range(3):
+        part.zero_grad(); part.training_step(batches[i], i); part.backward()
+        for name, p in o.named_parameters():                     # torch's Adam on the ENGINE's gradients: isolates the state layout
+            p.grad = part.grad(name).cpu().clone()
+        part.optimizer_step(); opt.step()
+        o.load_state_dict({k: v.cpu() for k, v in part.state_dict().items()}, strict=True)      # keep BN buffers / weights in step
+    sd = part.optimizer_state_dict()
+    ref = opt.state_dict()
+    assert sd["param_groups"][0]["params"] == ref["param_groups"][0]["params"] and set(sd["state"]) == set(ref["state"])
+    for i in ref["state"]:
+        assert float(sd["state"][i]["step"]) == float(ref["state"][i]["step"]) == 3.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.allclose(sd["state"][i][k], ref["state"][i][k], rtol=1e-5, atol=1e-9), (i, k)
+    torch.optim.Adam(o.parameters(), lr=1.0).load_state_dict(sd)                                   # torch accepts the layout
+    resumed = OCRModel(c2i, i2c, **dict(kw, init_seed=99))
+    resumed.use_graph = False
+    resumed.load_state_dict(part.state_dict(), strict=True)
+    resumed.load_optimizer_state_dict(sd)
+    assert resumed._optimizer.step_count == 3
+    for i in (3, 4):
+        resumed.fit_step(batches[i], i)
+    for name in full.offsets:
+        a, b = resumed.param(name), full.param(name)
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), name
+
+
 def test_training_step_accepts_whole_page_label_texts():
     """A page text of several hundred characters (what ocr_lightning's dataset yields) in the batch: the step runs, the long
     sample contributes rec loss 0 like nn.CTCLoss(zero_infinity=True) against one time step, the short ones still train."""
@@ -640,6 +681,16 @@ def test_cli_trains_the_ocr_model_on_a_folder_dataset(tmp_path):
     assert "feature_extractor.7.2.bn2.running_var" in ck["state_dict"] and ck["hyper_parameters"]["max_boxes"] == 5
     m = OCRModel(CHAR_TO_IDX, IDX_TO_CHAR, max_boxes=5)
     m.load_state_dict(ck["state_dict"], strict=True)
+    # --resume: weights, Adam state and epoch come back (pl.Trainer.fit(ckpt_path=...)); one more epoch is appended to the log
+    assert ck["epoch"] == 1 and len(ck["optimizer_states"][0]["state"]) == len(m.offsets) and ck["global_step"] == 4
+    r = subprocess.run([sys.executable, "-m", "kzv.train", "--model", "ocr", "--train_data_dir", str(tmp_path / "train"), "--val_data_dir", str(tmp_path / "val"),
+                        "--checkpoint_dir", str(tmp_path / "ck"), "--log_dir", str(tmp_path / "logs"), "--batch_size", "3", "--epochs", "3", "--max_boxes", "5",
+                        "--learning_rate", "1e-3", "--seed", "1", "--accelerator", "gpu", "--devices", "1", "--resume", str(tmp_path / "ck" / "last.ckpt")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "Traceback" not in r.stderr and "Resumed from" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    recs = [json.loads(ln) for ln in (tmp_path / "logs" / "metrics.jsonl").read_text().splitlines()]
+    assert [x["epoch"] for x in recs] == [0, 1, 2]
+    assert torch.load(tmp_path / "ck" / "last.ckpt", weights_only=False)["global_step"] == 6
 
 
 def test_two_rank_data_parallel_fit_steps(tmp_path):
