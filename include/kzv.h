@@ -315,6 +315,16 @@ typedef struct kzv_gemm_tn_args {
 } kzv_gemm_tn_args;
 int kzv_gemm_tn(const kzv_gemm_tn_args* a, void* stream);
 
+/* A Linear's input gradient (kzv_gemm_nt arguments, epilogue BF16 / F32 / RESID / DGELU) and weight gradient (kzv_gemm_tn arguments) from
+ * the same dY as ONE launch when both take the 256x256 kernels (>= 256 output tiles of the first, >= 9 of the second, 256 CUs): every
+ * workgroup runs its gemm_nt tiles and then a token range of one weight-gradient tile, sized on the host so that all workgroups finish
+ * together -- the two launches each end on a partly filled round otherwise.  Falls back to the two separate launches.  The gemm_nt
+ * result is bit-identical to kzv_gemm_nt's; the weight gradient differs by the bf16 rounding of its partial tiles (other token splits).
+ * model.cpp's encoder backward calls it per nn.Linear (HF vit:192-254).  OFF by default (kzv_set_pair(1) / KZV_PAIR=1 turn it on):
+ * measured +0.4 % img/s on the training step, one kernel boundary per pair and nothing from the balancing. */
+int kzv_gemm_dgrad_wgrad(const kzv_gemm_nt_args* nt, int epilogue, const kzv_gemm_tn_args* tn, void* stream);
+int kzv_set_pair(int on);
+
 /* The same two products on fp32 OPERANDS (A, B, P, Q are float; leading dimensions in elements, multiples of 4; K % 32 == 0 for
  * the NT form), on the f32-input matrix instruction: exact fp32 products, fp32 accumulation (csrc/gemm_f32.hip).  For the model of
  * ocr_lightning/model.py, which the reference trains in fp32 (ocr_lightning/train.py:132-140; its own test wants singles ==

@@ -409,7 +409,8 @@ static int nt_schedule() {
 }
 extern "C" int kzv_set_nt_schedule(int n) { g_nt_schedule = n < 0 ? -1 : (n != 0); return KZV_OK; }
 
-extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
+// validation of a kzv_gemm_nt call and its kernel parameter block (shared with the dgrad + wgrad pair launch of gemm_tn256.hip)
+int kzv_nt_params(const kzv_gemm_nt_args* a, int epilogue, NtParams* out) {
     if (!a || !a->A || !a->B || !a->C) return kzv_fail(KZV_E_ARG, "gemm_nt: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return kzv_fail(KZV_E_ARG, "gemm_nt: empty shape");
     if (a->K % 64) return kzv_fail(KZV_E_ARG, "gemm_nt: K must be a multiple of 64");
@@ -427,6 +428,13 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     kzv_drop_params(a->drop_p, &p.drop_thr16, &p.drop_inv_keep);
     p.drop_key = a->drop_key;
     p.strip = kzv_nt_strip() & 0xff;
+    *out = p;
+    return KZV_OK;
+}
+
+extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream) {
+    NtParams p;
+    { const int rc = kzv_nt_params(a, epilogue, &p); if (rc != KZV_OK) return rc; }
     hipStream_t s = (hipStream_t)stream;
     KzvProfScope prof(0, 2.0 * a->M * p.n_valid * a->K, s);
     // large shapes: 256x256 eight-phase kernels.  The persistent one wins wherever its per-wave drain is light (one

@@ -74,18 +74,20 @@ struct TileSrc {            // where the next half-tiles of one half index (h) c
     int kt, seq; bool valid;
 };
 
+// The kernel body as a device function (workgroup `bid` of `G`, the 160 KiB of dynamic LDS in `smem`): the plain kernel below
+// wraps it; gemm_tn256.hip's dgrad + wgrad pair kernel runs it as its first phase.  Every wave leaves it with no LDS-DMA in flight
+// and the barrier count balanced.
 template <int EPI, bool F8>
-__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN, const int strip_in) {
+__device__ __forceinline__ void nt256p_body(const NtParams& p, const int tiles, const int tilesN, const int strip_in, const int bid, const int G,
+                                            char* const smem) {
     const int strip = strip_in & 0xff;             // bit 8: the double-buffered bf16 drain (A/B knob KZV_BF16_DRAIN, default on)
     constexpr int ES = F8 ? 1 : 2;                 // bytes per operand element
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wr = w >> 2, wc = w & 3;
-    const int G = gridDim.x;
     // blocks land on XCD (blockIdx % 8): give each XCD a contiguous run of every step's tiles (shared A row panels)
-    const int vblk = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int vblk = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
     const int nk = p.K * ES / 128;                 // K-tiles of 128 bytes per row: even, >= 2 (checked by the launcher)
 
     auto set_tile = [&](TileSrc& s, int seq, int h) {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     bool credit = false;                            // previous drain was of an interior tile
 #ifdef KZV_STAMPS
     // per-block stamps: [blockIdx][16]: start, then (K loop end, drain end) per tile
-    unsigned long long* stp = (EPI == KZV_EPI_BF16 && tid == 0) ? (unsigned long long*)p.aux + blockIdx.x * 16 : nullptr;
+    unsigned long long* stp = (EPI == KZV_EPI_BF16 && tid == 0) ? (unsigned long long*)p.aux + bid * 16 : nullptr;
     int stk = 0;
 #define KZV_STAMP() do { if (stp) stp[stk++] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -417,7 +419,14 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, cons
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
 }
 
+template <int EPI, bool F8>
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(const NtParams p, const int tiles, const int tilesN, const int strip_in) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nt256p_body<EPI, F8>(p, tiles, tilesN, strip_in, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
 }  // namespace
+#ifndef KZV_NT256P_BODY_ONLY
 int kzv_nt_strip() {
     static int v = -1000;
     if (v == -1000) {
@@ -487,3 +496,4 @@ int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s) {
 #undef KZV_NT256P8_CASE
     return KZV_OK;
 }
+#endif  // KZV_NT256P_BODY_ONLY

@@ -30,8 +30,18 @@
 #include "../../include/kzv.h"
 #include "kzv_host.h"
 #include "gemm_tn.h"
+#include "gemm_nt.h"
 #include <vector>
 #include <cstdlib>
+#include <type_traits>
+
+// the persistent gemm_nt kernel's body, for the dgrad + wgrad pair kernel below (kernels of a translation unit cannot call into
+// another one's: the source is compiled here a second time, device functions only)
+namespace kzv_pair_nt {
+#define KZV_NT256P_BODY_ONLY
+#include "gemm_nt256p.hip"
+#undef KZV_NT256P_BODY_ONLY
+}  // namespace kzv_pair_nt
 
 namespace {
 
@@ -279,20 +289,14 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const TnParams p, float
 // LDS: P half-tiles [buf][h] in the first 64 KiB, Q in the second: six per-lane fragment addresses + 16-bit immediates.
 // DMA sources: per-lane (token row, clamped column) terms fixed for the kernel (4 registers), stage / piece terms in the SGPR base.
 // A stage index past the split's last stage is clamped (it re-reads the last stage into slots nobody reads again).
-__global__ __launch_bounds__(512) void gemm_tn256f_kernel(const TnParams p, float* part_ws) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Body as a device function: output tile (tnb, tkb), tokens t_begin .. t_begin + 64 * nt (nt >= 2 stages), partial tile -> `part`.
+__device__ __forceinline__ void tn256f_body(const TnParams& p, float* const part, const int tnb, const int tkb, const int t_begin, const int nt,
+                                            char* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wr = w >> 2, wc = w & 3;
-    const int tilesN = (p.N + 255) / 256, tilesK = (p.K + 255) / 256;
-    const int per = tilesN * tilesK;
-    const int id = xcd_remap(blockIdx.x, per * p.splits);
-    const int split = id / per, rem = id - split * per;
-    const int tnb = rem / tilesK, tkb = rem - tnb * tilesK;
-    const int t_begin = split * p.chunk;                      // chunk and Mtok are multiples of 64 (launcher)
-    const int t_end = min(p.Mtok, t_begin + p.chunk);
-    const int nt = (t_end - t_begin) >> 6;                    // >= 2 (launcher)
+    const int tilesK = (p.K + 255) / 256;
 
     const unsigned ldp2 = (unsigned)p.ldp * 2u, ldq2 = (unsigned)p.ldq * 2u;
     const char* baseP = (const char*)(p.P + (int64_t)t_begin * p.ldp);
@@ -455,7 +459,6 @@ __global__ __launch_bounds__(512) void gemm_tn256f_kernel(const TnParams p, floa
 
     // ---- epilogue: as gemm_tn256_kernel ----
     float* tile = (float*)smem;
-    float* part = part_ws + (size_t)id * PART_FLOATS;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         __syncthreads();
@@ -483,6 +486,41 @@ __global__ __launch_bounds__(512) void gemm_tn256f_kernel(const TnParams p, floa
 #endif
         }
     }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256f_kernel(const TnParams p, float* part_ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tilesN = (p.N + 255) / 256, tilesK = (p.K + 255) / 256;
+    const int per = tilesN * tilesK;
+    const int id = xcd_remap(blockIdx.x, per * p.splits);
+    const int split = id / per, rem = id - split * per;
+    const int t_begin = split * p.chunk;                      // chunk and Mtok are multiples of 64 (launcher)
+    const int t_end = min(p.Mtok, t_begin + p.chunk);
+    tn256f_body(p, part_ws + (size_t)id * PART_FLOATS, rem / tilesK, rem % tilesK, t_begin, (t_end - t_begin) >> 6, smem);      // >= 2 stages (launcher)
+}
+
+// ---- one launch for a layer's input-gradient GEMM and its weight-gradient GEMM (round 4) ------------------
+// Both read the same dY and neither reads the other's output.  As two launches each ends on a partly filled round: the persistent
+// gemm_nt gives its 256 workgroups 5 or 6 (1 or 2, 7 or 8) tiles each and the workgroups with the smaller count idle for a tile
+// time (~6 % of the launch), the weight gradient runs on 243 - 252 of the 256 CUs, and a kernel boundary sits between them.  Here
+// every workgroup runs its gemm_nt tiles (nt256p_body) and then ONE token range of ONE weight-gradient tile (tn256f_body) whose
+// length the host sizes so that all workgroups finish together: a workgroup that had one tile less gets `r` stages more (r = the
+// tile's duration in stages).  The plan (tile, split, first stage, stage count per workgroup) is a kernel argument.
+// The workgroups that share a weight-gradient tile ROW and a split index take the same token range (the bias gradient is
+// partitioned over them by stage index); their gemm_nt tile counts are equal except at one boundary (the ids are contiguous).
+struct PairPlan { unsigned short tile[256], split[256], t0[256], cnt[256]; };      // by blockIdx; cnt == 0: no weight-gradient share
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pair_kernel(const NtParams pn, const int tiles, const int tilesN, const int strip_in, const TnParams pt,
+                                                        float* part_ws, const int per, const PairPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    kzv_pair_nt::nt256p_body<EPI, false>(pn, tiles, tilesN, strip_in, (int)blockIdx.x, (int)gridDim.x, smem);
+    const int cnt = plan.cnt[blockIdx.x];
+    if (cnt == 0) return;
+    __syncthreads();                               // every wave is done with the gemm_nt ring and drain patches
+    const int tile = plan.tile[blockIdx.x], split = plan.split[blockIdx.x];
+    const int tilesK = (pt.K + 255) / 256;
+    tn256f_body(pt, part_ws + ((size_t)split * per + tile) * PART_FLOATS, tile / tilesK, tile % tilesK, (int)plan.t0[blockIdx.x] * 64, cnt, smem);
 }
 
 // OUT[n][k] += sum over splits of the partial tiles (4 columns per thread, one 1-KiB row segment per wave-instruction)
@@ -639,6 +677,129 @@ int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
     return 1;
 }
 
+// gemm.hip: the parameter block of a kzv_gemm_nt call (validated there)
+int kzv_nt_params(const kzv_gemm_nt_args* a, int epilogue, NtParams* out);
+
+namespace {
+int g_pair = -1;
+int pair_enabled() {
+    // default OFF: measured on the step's four encoder pairs (tools/dev/r4_pair.py, same-box A/B): -23 us per layer at best (one kernel
+    // boundary per pair), +0.4 % img/s on the whole step -- and NO gain from sizing the token ranges to the gemm_nt tile counts (the
+    // workgroups that leave the gemm_nt phase early then run their weight-gradient stages beside the others' gemm_nt tiles, and the
+    // two loops slow each other as they do on two streams).  DESIGN.md section 8.
+    if (g_pair < 0) { const char* e = getenv("KZV_PAIR"); g_pair = e ? (atoi(e) != 0) : 0; }
+    return g_pair;
+}
+// stages of the weight-gradient loop one gemm_nt tile is worth: (K-tiles x 1.45 us + drain) / 1.55 us per stage; KZV_PAIR_R overrides (x 0.01)
+double pair_ratio(int nk, int epilogue) {
+    static int ov = -2;
+    if (ov == -2) { const char* e = getenv("KZV_PAIR_R"); ov = e ? atoi(e) : -1; }
+    const double drain = (epilogue == KZV_EPI_DGELU || epilogue == KZV_EPI_RESID) ? 5.0 : 2.5;
+    const double r = 0.6 * (nk * 1.45 + drain) / 1.55;          // 0.6: the best of a sweep over 0 / 0.6 / 1 / 1.4 / 2 (flat between 0 and 0.6)
+    return ov >= 0 ? r * ov * 0.01 / 0.6 : r;
+}
+}  // namespace
+
+// 1 = launched as one kernel; 0 = not taken (the caller issues the two GEMMs separately); < 0 = error
+int kzv_gemm_pair_launch(const kzv_gemm_nt_args* na, int epilogue, const kzv_gemm_tn_args* ta, hipStream_t s) {
+    if (!pair_enabled() || kzv_cu_reserve() != 0 || !tn_schedule() || device_cus() != 256) return 0;
+    if (epilogue != KZV_EPI_BF16 && epilogue != KZV_EPI_F32 && epilogue != KZV_EPI_DGELU && epilogue != KZV_EPI_RESID) return 0;
+    NtParams pn;
+    if (kzv_nt_params(na, epilogue, &pn) != KZV_OK) return 0;
+    // the conditions of kzv_nt256p_launch ...
+    const int tilesN = (pn.N + 255) / 256, tiles = ((pn.M + 255) / 256) * tilesN;
+    if (pn.K < 128 || pn.K % 128 || tiles < 256) return 0;
+    if ((uint64_t)256 * (uint64_t)pn.lda * 2 > 0xffffffffull || (uint64_t)pn.n_valid * (uint64_t)pn.ldb * 2 > 0xffffffffull) return 0;
+    // ... and of kzv_tn256_launch
+    TnParams pt{};
+    pt.P = (const bf16_t*)ta->P; pt.Q = (const bf16_t*)ta->Q; pt.OUT = ta->OUT; pt.zero16 = kzv_zero_page();
+    pt.ldp = ta->ldp; pt.ldq = ta->ldq; pt.ldo = ta->ldo; pt.Mtok = ta->Mtok; pt.N = ta->N; pt.K = ta->K;
+    pt.n_store = ta->n_store > 0 ? ta->n_store : ta->N; pt.dbias = ta->dbias;
+    if (!pt.P || !pt.Q || !pt.OUT || !pt.zero16) return 0;
+    const int tilesKw = (pt.K + 255) / 256, tilesNw = (pt.N + 255) / 256, per = tilesNw * tilesKw;
+    const int stages = pt.Mtok / 64;
+    if (per < tn256_min_tiles() || per > 128 || pt.Mtok % 64 || pt.N < 8 || pt.K < 8 || pt.N % 8 || pt.K % 8) return 0;
+    if ((uint64_t)64 * (uint64_t)pt.ldp * 2 + (uint64_t)pt.N * 2 > 0xffffffffull || (uint64_t)64 * (uint64_t)pt.ldq * 2 + (uint64_t)pt.K * 2 > 0xffffffffull) return 0;
+    if (pt.K % 4 || pt.ldo % 4 || ((uintptr_t)pt.OUT & 15) || ((uintptr_t)pt.P & 15) || ((uintptr_t)pt.Q & 15) || pt.ldp % 8 || pt.ldq % 8) return 0;
+    const int G = 256, S = G / per;
+    if (S < 1 || stages < 8 * S || stages > 65000) return 0;
+    // ---- the plan ----
+    PairPlan plan;
+    int cb[256], idb[256];
+    const int nwg = per * S;
+    for (int b = 0; b < G; ++b) {
+        const int vblk = (b & 7) * (G >> 3) + (b >> 3);
+        cb[b] = vblk < tiles ? (tiles - 1 - vblk) / G + 1 : 0;
+        idb[b] = -1;
+        plan.tile[b] = plan.split[b] = plan.t0[b] = plan.cnt[b] = 0;
+        if (b < nwg) {
+            const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;                      // kzv_common.h xcd_remap
+            idb[b] = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        }
+    }
+    const double r = pair_ratio(pn.K / 64, epilogue);
+    std::vector<int> cg((size_t)tilesNw * S, 0);                                    // gemm_nt tiles of the group (tile row, split): the largest of its members
+    for (int b = 0; b < nwg; ++b) { const int sp = idb[b] / per, tl = idb[b] % per; int& c = cg[(size_t)(tl / tilesKw) * S + sp]; c = cb[b] > c ? cb[b] : c; }
+    std::vector<int> t0((size_t)tilesNw * S), cnt((size_t)tilesNw * S);
+    for (int tn = 0; tn < tilesNw; ++tn) {
+        double csum = 0;
+        for (int sp = 0; sp < S; ++sp) csum += cg[(size_t)tn * S + sp];
+        const double level = (stages + r * csum) / S;                               // the common finishing time, in stages
+        double acc = 0; int prev = 0;
+        for (int sp = 0; sp < S; ++sp) {
+            double n = level - r * cg[(size_t)tn * S + sp];
+            if (n < 2) n = 2;
+            acc += n;
+            int end = sp == S - 1 ? stages : (int)(acc + 0.5);
+            const int left = S - 1 - sp;                                             // every later split keeps >= 2 stages
+            if (end > stages - 2 * left) end = stages - 2 * left;
+            if (end < prev + 2) end = prev + 2;
+            t0[(size_t)tn * S + sp] = prev; cnt[(size_t)tn * S + sp] = end - prev; prev = end;
+        }
+        if (prev != stages) return 0;
+    }
+    for (int b = 0; b < nwg; ++b) {
+        const int sp = idb[b] / per, tl = idb[b] % per; const size_t gi = (size_t)(tl / tilesKw) * S + sp;
+        plan.tile[b] = (unsigned short)tl; plan.split[b] = (unsigned short)sp; plan.t0[b] = (unsigned short)t0[gi]; plan.cnt[b] = (unsigned short)cnt[gi];
+    }
+    pt.splits = S; pt.chunk = 0;
+    // ---- workspace / fold bookkeeping of kzv_tn256_launch ----
+    const size_t need = (size_t)per * S * PART_FLOATS;
+    const bool deferred = g_tn_defer > 0;
+    bool same_out = false;
+    for (const TnFold& e : g_tn_pending) same_out |= e.OUT == pt.OUT;
+    if (deferred && ((int)g_tn_pending.size() == TN_REGIONS - 1 || need > g_tn_region || same_out)) {
+        if (tn_flush(s) != KZV_OK) return 0;
+    }
+    float* ws = tn_partials(need, deferred ? 1 + (int)g_tn_pending.size() : 0);
+    if (!ws) return 0;
+    KzvProfScope prof(5, 2.0 * pn.M * pn.n_valid * pn.K + 2.0 * pt.Mtok * pt.N * pt.K, s);
+    constexpr int PAIR_LDS = 160 * 1024;
+#define KZV_PAIR_CASE(E)                                                                                            \
+    case E: {                                                                                                       \
+        static bool attr_done = false;                                                                              \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_pair_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS); attr_done = true; } \
+        hipLaunchKernelGGL((gemm_pair_kernel<E>), dim3(G), dim3(512), PAIR_LDS, s, pn, tiles, tilesN, kzv_nt_strip(), pt, ws, per, plan);   \
+    } break;
+    switch (epilogue) {
+        KZV_PAIR_CASE(KZV_EPI_BF16) KZV_PAIR_CASE(KZV_EPI_F32) KZV_PAIR_CASE(KZV_EPI_DGELU) KZV_PAIR_CASE(KZV_EPI_RESID)
+        default: return 0;
+    }
+#undef KZV_PAIR_CASE
+    if (deferred) g_tn_pending.push_back(TnFold{ws, pt.OUT, pt.ldo, pt.n_store, pt.K, tilesKw, per, S, 0});
+    else hipLaunchKernelGGL(gemm_tn256_fold_kernel, dim3(per * 64), dim3(256), 0, s, ws, pt.OUT, pt.ldo, pt.n_store, pt.K, tilesKw, per, S);
+    return kzv_check_launch("gemm_pair") == KZV_OK ? 1 : -1;
+}
+
+extern "C" int kzv_set_pair(int n) { g_pair = n < 0 ? -1 : (n != 0); return KZV_OK; }
+extern "C" int kzv_gemm_dgrad_wgrad(const kzv_gemm_nt_args* na, int epilogue, const kzv_gemm_tn_args* ta, void* stream) {
+    if (!na || !ta) return kzv_fail(KZV_E_ARG, "gemm_dgrad_wgrad: null");
+    const int rc = kzv_gemm_pair_launch(na, epilogue, ta, (hipStream_t)stream);
+    if (rc < 0) return kzv_fail(KZV_E_HIP, "gemm_dgrad_wgrad: pair launch");
+    if (rc == 1) return KZV_OK;
+    const int r2 = kzv_gemm_tn(ta, stream);
+    return r2 != KZV_OK ? r2 : kzv_gemm_nt(na, epilogue, stream);
+}
 extern "C" int kzv_set_tn_schedule(int n) { g_tn_schedule = n < 0 ? -1 : (n != 0); return KZV_OK; }
 
 KzvTnFoldScope::KzvTnFoldScope(hipStream_t stream) : s(stream) { ++g_tn_defer; }

@@ -419,6 +419,28 @@ int join_side(kzv_model* m, hipStream_t s) {
     return KZV_OK;
 }
 
+// A Linear's input gradient (gemm_nt against the transposed weight, one-store epilogue) and weight gradient (gemm_tn) from the same dY:
+// ONE launch when gemm_tn256.hip's pair kernel takes the shapes (kzv_gemm_pair_launch), else the two launches in the order the
+// single-stream schedule has always issued them (weight gradient first).
+int dgrad_wgrad(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t ldy, const W16& w, int Mtok, int Nout, int Kin, void* dX, int64_t ldx,
+                int epi, void* aux, int64_t ldaux, const bf16_t* X, int64_t ldxq, float* dW, float* dbias) {
+    // dX[Mtok, Kin] = dY[Mtok, Nout] . W[Nout, Kin]  (B operand = W^T copy [Kin, Nout]);  dW[Nout, Kin] += dY^T . X
+    if (!m->use_side && !m->fp8) {
+        kzv_gemm_nt_args na;
+        memset(&na, 0, sizeof(na));
+        na.A = dY; na.lda = ldy; na.B = w.wt; na.ldb = w.ldt; na.C = dX; na.ldc = ldx; na.ldr = ldx; na.aux = aux; na.ldaux = ldaux;
+        na.M = Mtok; na.N = Kin; na.K = Nout; na.n_valid = Kin;
+        kzv_gemm_tn_args ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.P = dY; ta.ldp = ldy; ta.Q = X; ta.ldq = ldxq; ta.OUT = dW; ta.ldo = Kin; ta.Mtok = Mtok; ta.N = Nout; ta.K = Kin; ta.n_store = Nout; ta.dbias = dbias;
+        const int rc = kzv_gemm_pair_launch(&na, epi, &ta, s);
+        if (rc < 0) return kzv_fail(KZV_E_HIP, "dgrad_wgrad: pair launch");
+        if (rc == 1) return KZV_OK;
+    }
+    KZV_TRY(wgrad_async(m, cls, s, dY, ldy, X, ldxq, dW, Mtok, Nout, Kin, Nout, dbias));
+    return gemm(dY, ldy, w, true, Mtok, Kin, Nout, Kin, nullptr, dX, ldx, epi, s, nullptr, aux, ldaux);
+}
+
 int attn(const kzv_model* m, bool bwd, int mode, const bf16_t* Q, int64_t ldq, const bf16_t* K, const bf16_t* V, int64_t ldkv,
          bf16_t* O, int64_t ldo, float* LSE, const bf16_t* dO, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int heads, int Sq, int Sk,
          float drop_p, uint32_t drop_key, hipStream_t s, int batch = 0, int head_dim = 64) {
@@ -678,29 +700,29 @@ int backward_enc_layer(kzv_model* m, int i, hipStream_t s) {
     }
     // x_out = x_mid + drop(fc2(gelu(fc1(LN2(x_mid)))))
     // on entry dy_e = dropout-masked bf16 copy of dx_e for this layer's fc2 site (written by the LN backward above it)
-    KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, G + e.fc2b));
-    KZV_TRY(wait_cls(m, CLS_DBIG, s));
     const bool f8g = m->fp8 >= 2 && !m->use_side;       // e4m3 input-gradient GEMMs of the MLP (the weight gradients keep reading bf16)
-    if (f8g)
+    if (f8g) {
+        KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.act, Fe, G + e.fc2w, Me, He, Fe, He, G + e.fc2b));
+        KZV_TRY(wait_cls(m, CLS_DBIG, s));
         KZV_TRY(gemm8(m->dy8, He, m->dy8_scale, m->w8t_fc2[i], Me, Fe, He, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe, 0.f, 0,
                       m->dbig8, nullptr, nullptr, m->dy8_rq));
-    else
-    KZV_TRY(gemm(m->dy_e, He, m->w_efc2[i], true, Me, Fe, He, Fe, nullptr, m->dbig_e, Fe, KZV_EPI_DGELU, s, nullptr, a.pre, Fe));
-    KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
-    if (f8g) KZV_TRY(gemm8(m->dbig8, Fe, m->dy8_rqinv, m->w8t_fc1[i], Me, He, Fe, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
-    else
-    KZV_TRY(gemm(m->dbig_e, Fe, m->w_efc1[i], true, Me, He, Fe, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+        KZV_TRY(wgrad_async(m, CLS_DBIG, s, m->dbig_e, Fe, a.ln2, He, G + e.fc1w, Me, Fe, He, Fe, G + e.fc1b));
+        KZV_TRY(gemm8(m->dbig8, Fe, m->dy8_rqinv, m->w8t_fc1[i], Me, He, Fe, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+    } else {
+        // each Linear's input gradient and weight gradient read the same dY: one launch per pair where the 256x256 kernels take both
+        KZV_TRY(wait_cls(m, CLS_DBIG, s));
+        KZV_TRY(dgrad_wgrad(m, CLS_DY, s, m->dy_e, He, m->w_efc2[i], Me, He, Fe, m->dbig_e, Fe, KZV_EPI_DGELU, a.pre, Fe, a.act, Fe, G + e.fc2w, G + e.fc2b));
+        KZV_TRY(dgrad_wgrad(m, CLS_DBIG, s, m->dbig_e, Fe, m->w_efc1[i], Me, Fe, He, m->dh_e, He, KZV_EPI_BF16, nullptr, 0, a.ln2, He, G + e.fc1w, G + e.fc1b));
+    }
     KZV_TRY(wait_cls(m, CLS_DY, s));      // dy_e is rewritten below
     KZV_TRY(kzv_ln_bwd_ex(m->dh_e, 0, a.x_mid, a.st2, P + e.ln2w, m->dx_e, 1, G + e.ln2w, G + e.ln2b, Me, He, 1, 0, 0.f, 0, s,
                           m->dy_e, dp(m, c.enc_hidden_dropout), key(m, SITE_ENC_L + 4 * i + 1)));
     // x_mid = x_in + drop(o(attn(qkv(LN1(x_in)))))
-    KZV_TRY(wgrad_async(m, CLS_DY, s, m->dy_e, He, a.ctx, He, G + e.ow, Me, He, He, He, G + e.ob));
-    KZV_TRY(gemm(m->dy_e, He, m->w_eo[i], true, Me, He, He, He, nullptr, m->dctx_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(dgrad_wgrad(m, CLS_DY, s, m->dy_e, He, m->w_eo[i], Me, He, He, m->dctx_e, He, KZV_EPI_BF16, nullptr, 0, a.ctx, He, G + e.ow, G + e.ob));
     KZV_TRY(wait_cls(m, CLS_DQKV, s));    // dqkv_e is rewritten below
     KZV_TRY(attn(m, true, 0, a.qkv, 3 * He, a.qkv + He, a.qkv + 2 * He, 3 * He, a.ctx, He, a.lse, m->dctx_e, m->dqkv_e, m->dqkv_e + He,
                  m->dqkv_e + 2 * He, c.enc_heads, m->Sa, m->Sa, dp(m, c.enc_attn_dropout), key(m, SITE_ENC_L + 4 * i), s, 0, He / c.enc_heads));
-    KZV_TRY(wgrad_async(m, CLS_DQKV, s, m->dqkv_e, 3 * He, a.ln1, He, G + e.qkvw, Me, 3 * He, He, 3 * He, G + e.qkvb));
-    KZV_TRY(gemm(m->dqkv_e, 3 * He, m->w_eqkv[i], true, Me, He, 3 * He, He, nullptr, m->dh_e, He, KZV_EPI_BF16, s));
+    KZV_TRY(dgrad_wgrad(m, CLS_DQKV, s, m->dqkv_e, 3 * He, m->w_eqkv[i], Me, 3 * He, He, m->dh_e, He, KZV_EPI_BF16, nullptr, 0, a.ln1, He, G + e.qkvw, G + e.qkvb));
     // ... and the masked copy for the fc2 site of the layer below (layer 0 hands fp32 dx_e to the embedding backward)
     KZV_TRY(wait_cls(m, CLS_DY, s));
     const KzvLnBwdF8 f8n{m->dy8, m->dy8_scale, m->dy8_rq, m->dy8_rqinv, (m->f8_wnorm && i > 0) ? m->f8_wnorm + (i - 1) : nullptr};

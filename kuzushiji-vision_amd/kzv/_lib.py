@@ -134,6 +134,8 @@ SYMBOLS = {
     "kzv_debug_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "kzv_debug_attn_dropout_mask": (C.c_int, [C.c_uint32, C.c_float, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     # ---- ocr_lightning/model.py path (csrc/ocr.hip)
+    "kzv_gemm_dgrad_wgrad": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, C.POINTER(kzv_gemm_tn_args), _P]),
+    "kzv_set_pair": (C.c_int, [C.c_int]),
     "kzv_gemm_nt_f32": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
     "kzv_gemm_tn_f32": (C.c_int, [C.POINTER(kzv_gemm_tn_args), _P]),
     "kzv_ocr_set_precision": (C.c_int, [C.c_int]),

@@ -203,6 +203,43 @@ def test_gemm_tn_large_outputs_take_the_256x256_kernel(lib, Mt, N, K):
         assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize("Nout,Kin,epi", [(768, 3072, "dgelu"), (2304, 768, "bf16"), (768, 768, "f32")])
+def test_dgrad_wgrad_pair_launch_equals_the_two_launches(lib, Nout, Kin, epi):
+    """kzv_gemm_dgrad_wgrad with the pair kernel on (kzv_set_pair(1); off by default): the input gradient is bit-identical
+    to kzv_gemm_nt's, the weight gradient within the bf16-partial tolerance of fp32 math (its token splits differ from kzv_gemm_tn's),
+    the bias gradient equal to 1e-5; accumulates INTO dW; run-to-run identical."""
+    M = 33024
+    torch.manual_seed(Nout + Kin)
+    dY = torch.randn(M, Nout, device=DEV).bfloat16(); X = torch.randn(M, Kin, device=DEV).bfloat16()
+    Wt = (torch.randn(Kin, Nout, device=DEV) * 0.05).bfloat16()
+    dt = torch.float32 if epi == "f32" else torch.bfloat16
+    dX = torch.empty(M, Kin, dtype=dt, device=DEV)
+    aux = (torch.rand(M, Kin, device=DEV) * 1.2).bfloat16() if epi == "dgelu" else None
+    base = torch.randn(Nout, Kin, device=DEV)
+    code = {"bf16": L.EPI_BF16, "f32": L.EPI_F32, "dgelu": L.EPI_DGELU}[epi]
+
+    def run(pair):
+        dW, db = base.clone(), torch.zeros(Nout, device=DEV)
+        na = L.kzv_gemm_nt_args(A=dY.data_ptr(), lda=Nout, B=Wt.data_ptr(), ldb=Nout, C=dX.data_ptr(), ldc=Kin, bias=None, resid=None, ldr=Kin,
+                                aux=L.ptr(aux), ldaux=Kin, M=M, N=Kin, K=Nout, n_valid=Kin, drop_p=0.0, drop_key=0)
+        ta = L.kzv_gemm_tn_args(P=dY.data_ptr(), ldp=Nout, Q=X.data_ptr(), ldq=Kin, OUT=dW.data_ptr(), ldo=Kin, Mtok=M, N=Nout, K=Kin, n_store=Nout, dbias=db.data_ptr())
+        L.check(lib.kzv_set_pair(pair), "set_pair")
+        dX.zero_()
+        L.check(lib.kzv_gemm_dgrad_wgrad(C.byref(na), code, C.byref(ta), _st()), "dgrad_wgrad")
+        torch.cuda.synchronize()
+        return dX.clone(), dW, db
+    try:
+        sx, sw, sb = run(0)
+        px, pw, pb = run(1)
+        px2, pw2, _ = run(1)
+    finally:
+        L.check(lib.kzv_set_pair(-1), "set_pair")
+    assert torch.equal(px, sx) and torch.equal(px2, px) and torch.equal(pw2, pw)
+    want = dY.float().t() @ X.float() + base
+    assert (pw - want).abs().max().item() < 4e-3 * want.abs().max().item() + 2e-3
+    assert (pb - sb).abs().max().item() < 1e-5 * sb.abs().max().item() + 1e-4
+
+
 @pytest.mark.parametrize("schedule", [0, 1])
 def test_gemm_tn256_schedules_agree_bit_for_bit_and_cancelling_partials_are_bounded(lib, schedule):
     """(1) The free-running stage schedule (kzv_set_tn_schedule(1), the default since round 4) and the eight-phase ping-pong produce
