@@ -178,6 +178,12 @@ int kzv_set_decode_one_launch(int on);
  * per layer (csrc/decoder_chain.hip; hidden 256, 4 heads, FFN 768) instead of nine.  1 (default; KZV_DEC_CHAIN), 0: one launch per
  * operation, -1: the environment's default.  Same tensors, same rounding points, same dropout bits. */
 int kzv_set_dec_chain(int on);
+/* Training / validation forward without returned logits: lm_head.decoder (HF modeling_roberta.py:888-893, tied weight) + log-softmax +
+ * NLL (src/models/trocr_model.py:256,292) + the bf16 gradient of the logits as ONE launch; the [B*T, vocab] fp32 logits are never written
+ * (csrc/decoder_chain.hip head_ce_kernel: 64 rows per workgroup against the whole vocabulary twice, online softmax statistics; decoder
+ * hidden 256).  1 (default; KZV_HEAD_CE), 0: head GEMM + ce_kernel, -1: the environment's default.  kzv_forward_loss with d_logits != NULL
+ * always takes the GEMM (it returns them).  Same arithmetic up to fp32 summation order. */
+int kzv_set_head_ce(int on);
 int kzv_decode_step_graph(kzv_model* m, const int64_t* d_tokens, const int32_t* d_posids, const uint8_t* d_valid, int64_t ld_valid,
                           float* d_logits, void* stream);
 

@@ -291,9 +291,156 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     CH_STAMP(11);
 }
 
+// ---- LM head + cross-entropy in one launch, logits never materialised (round 4, VERDICT r03 "missing" 1) -------------
+// Replaces, for a training / validation step that does not return logits: lm_head.decoder (HF modeling_roberta.py:888-893, tied to the
+// word embeddings) + CrossEntropyLoss(ignore_index = pad) (src/models/trocr_model.py:256,292) -- a [B*T, 4352] fp32 logits tensor written
+// by the GEMM (267 MB at T = 60), read back by ce_kernel, and the bf16 gradient written behind it.  Rows are independent: one workgroup
+// takes 64 rows of the head's LayerNorm output (bf16, in LDS) against the whole vocabulary twice, 256 columns at a time, the tied
+// weight arriving in fragment order from L2 (2.2 MB, shared by every workgroup) through chain_gemm's window:
+//   pass 1: logits chunk -> per-lane online (max, sum exp) over the lane's own columns, the target's logit picked out on the way;
+//           the 32 partial pairs of a row (8 waves x 4 lane groups) meet in LDS -> lse[row]; loss += (lse - logit[target]) / count
+//   pass 2: the same chunks again -> (exp(logit - lse) - onehot) / count as bf16 through an LDS tile, whole rows out (dlogits, the
+//           operand of the head's two gradient GEMMs).  Skipped without a gradient buffer (validation).
+// Same arithmetic as gemm_nt + ce_kernel up to fp32 summation order (bf16 operands, fp32 accumulation, fp32 softmax statistics).
+struct HeadCE {
+    const bf16_t* x; const bf16_t* wp; const float* bias; const int64_t* labels; const float* count; float* loss; bf16_t* dlogits;
+    int M, L, T, V, Vp, nch, pad;
+};
+__global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* a1 = (bf16_t*)smem;                                   // [RM][LDH] the rows' operand tile
+    bf16_t* stage = (bf16_t*)(smem + LDS_A1);                     // [RM][LDH] one chunk of dlogits on its way out
+    float* red = (float*)(smem + 2 * LDS_A1);                     // [RM][32][2] partial (max, sum) pairs
+    float* lse_s = red + RM * 64;                                 // [RM]
+    float* tl_s = lse_s + RM;                                     // [RM] the target's logit
+    int* tgt_s = (int*)(tl_s + RM);                               // [RM] target class, -1 = ignored row
+    const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * RM;
+    bf16x8 R[WIN];
+    fill_window<2, 8>(R, wave_frags<2, 8>(p.wp, w), opaque(lane0));
+    load_rows(p.x, a1, m0, p.M, opaque(tid));
+    if (tid < RM) {
+        const int m = m0 + tid;
+        int t = -1;
+        if (m < p.M) {
+            const int b = m / p.T, pos = m - b * p.T;
+            const int64_t g = p.labels[(int64_t)b * p.L + pos + 1];
+            t = (g == p.pad || g < 0 || g >= p.V) ? -1 : (int)g;
+        }
+        tgt_s[tid] = t; tl_s[tid] = 0.f;
+    }
+    wg_barrier();
+    const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
+    int tg[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) tg[rt] = tgt_s[rt * 16 + l15];
+    const float inv_cnt = 1.f / *p.count;
+    // the chunk's logits of this lane: v[c][rt][r] at column n0(c) + r, row rt * 16 + l15; columns >= V -> -inf
+    auto chunk_logits = [&](int j, const f32x4 (&acc)[2][RT], float (&v)[2][RT][4]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n0 = j * 256 + (w + 8 * c) * 16 + 4 * g;
+            float bb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bb[r] = n0 + r < p.V ? p.bias[n0 + r] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[c][rt][r] = n0 + r < p.V ? acc[c][rt][r] + bb[r] : -INFINITY;
+        }
+    };
+    // ---- pass 1 ----
+    float mrun[RT], lrun[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { mrun[rt] = -INFINITY; lrun[rt] = 0.f; }
+#pragma unroll 1
+    for (int j = 0; j < p.nch; ++j) {
+        f32x4 acc[2][RT];
+        const bf16_t* nextw = p.wp + (int64_t)(j + 1 < p.nch ? j + 1 : 0) * 65536;          // the last chunk prefetches pass 2's first
+        chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(nextw, w), a1, LDH, lane, acc);
+        float v[2][RT][4];
+        chunk_logits(j, acc, v);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float mx = mrun[rt];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, v[c][rt][r]);
+            if (mx > -INFINITY) {
+                float sacc = lrun[rt] * __expf(mrun[rt] - mx);            // (exp(-inf - finite) = 0 on the first finite chunk)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc += __expf(v[c][rt][r] - mx);
+                lrun[rt] = sacc; mrun[rt] = mx;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int n0 = j * 256 + (w + 8 * c) * 16 + 4 * g;
+                const int d = tg[rt] - n0;
+                if (d >= 0 && d < 4) tl_s[rt * 16 + l15] = d == 0 ? v[c][rt][0] : d == 1 ? v[c][rt][1] : d == 2 ? v[c][rt][2] : v[c][rt][3];
+            }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float* q = red + ((rt * 16 + l15) * 32 + w * 4 + g) * 2;
+        q[0] = mrun[rt]; q[1] = lrun[rt];
+    }
+    wg_barrier();
+    if (tid < RM) {                                   // one thread per row folds the 32 pairs in a fixed order
+        float mx = -INFINITY;
+        for (int k = 0; k < 32; ++k) mx = fmaxf(mx, red[(tid * 32 + k) * 2]);
+        float se = 0.f;
+        for (int k = 0; k < 32; ++k) se += red[(tid * 32 + k) * 2 + 1] * __expf(red[(tid * 32 + k) * 2] - mx);
+        const float lse = mx + __logf(se);
+        lse_s[tid] = lse;
+        float contrib = tgt_s[tid] >= 0 ? (lse - tl_s[tid]) * inv_cnt : 0.f;
+        contrib = wave_sum(contrib);
+        if (tid == 0) atomicAdd(p.loss, contrib);
+    }
+    if (!p.dlogits) return;                           // wave-uniform (a kernel argument)
+    wg_barrier();
+    float ls[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ls[rt] = lse_s[rt * 16 + l15];
+    // ---- pass 2 ----
+#pragma unroll 1
+    for (int j = 0; j < p.nch; ++j) {
+        f32x4 acc[2][RT];
+        if (j + 1 < p.nch) chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(p.wp + (int64_t)(j + 1) * 65536, w), a1, LDH, lane, acc);
+        else chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), nullptr, a1, LDH, lane, acc);
+        float v[2][RT][4];
+        chunk_logits(j, acc, v);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int nl = (w + 8 * c) * 16 + 4 * g, n0 = j * 256 + nl;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = tg[rt] >= 0 ? (__expf(v[c][rt][r] - ls[rt]) - (n0 + r == tg[rt] ? 1.f : 0.f)) * inv_cnt : 0.f;      // exp(-inf) = 0: padded columns
+                *(uint2*)(stage + (rt * 16 + l15) * LDH + nl) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+        wg_barrier();
+        {                                             // whole rows out: 16 bytes per lane, only the columns dlogits has (Vp may end inside the chunk)
+            const int pieces = min(32, (p.Vp - j * 256) / 8);
+            const int t2 = opaque(tid);
+#pragma unroll
+            for (int q = 0; q < RM * 32 / 512; ++q) {
+                const int idx = t2 + q * 512, row = idx >> 5, ch = idx & 31;
+                if (m0 + row < p.M && ch < pieces) *(uint4*)(p.dlogits + (int64_t)(m0 + row) * p.Vp + j * 256 + ch * 8) = *(const uint4*)(stage + row * LDH + ch * 8);
+            }
+        }
+        wg_barrier();
+    }
+}
+
 // every decoder weight of the model -> fragment order, one launch
-struct PackDesc { const uint4* src; uint4* dst; int N, K, t0; };
-struct PackTable { PackDesc d[6 * KZV_DECODE_FUSED_MAX_LAYERS + 1]; int n; };
+struct PackDesc { const uint4* src; uint4* dst; int N, K, t0, n_valid; };
+struct PackTable { PackDesc d[6 * KZV_DECODE_FUSED_MAX_LAYERS + 2]; int n; };
 __global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -302,7 +449,8 @@ __global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
     const PackDesc& d = tab.d[k];
     const int u = t - d.t0, lane = u & 63, f = u >> 6, KS = d.K / 32;
     const int nb = f / KS, ks = f - nb * KS;
-    d.dst[u] = d.src[((int64_t)(nb * 16 + (lane & 15)) * d.K + ks * 32 + (lane >> 4) * 8) / 8];
+    const int row = nb * 16 + (lane & 15);                      // rows beyond n_valid (the vocabulary's padding) pack as zeros
+    d.dst[u] = row < d.n_valid ? d.src[((int64_t)row * d.K + ks * 32 + (lane >> 4) * 8) / 8] : make_uint4(0, 0, 0, 0);
 }
 
 }  // namespace
@@ -342,13 +490,25 @@ int kzv_dec_chain_b(const KzvDecChainB& a, hipStream_t s) {
     return kzv_check_launch("dec_chain_b");
 }
 
+int kzv_head_ce(const KzvHeadCE& a, hipStream_t s) {
+    if (!a.x || !a.wp || !a.bias || !a.labels || !a.count || !a.loss || a.M < 1 || a.V < 1 || a.Vp % 8 || a.Vp < a.V) return kzv_fail(KZV_E_ARG, "head_ce: bad argument");
+    HeadCE p;
+    p.x = a.x; p.wp = a.wp; p.bias = a.bias; p.labels = a.labels; p.count = a.count; p.loss = a.loss; p.dlogits = a.dlogits;
+    p.M = a.M; p.L = a.L; p.T = a.T; p.V = a.V; p.Vp = a.Vp; p.nch = (a.V + 255) / 256; p.pad = a.pad;
+    constexpr int LDS_H = 2 * LDS_A1 + RM * 64 * 4 + RM * 4 * 3;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)head_ce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H); attr_done = true; }
+    hipLaunchKernelGGL(head_ce_kernel, dim3((a.M + RM - 1) / RM), dim3(512), LDS_H, s, p);
+    return kzv_check_launch("head_ce");
+}
+
 int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s) {
-    if (n < 1 || n > 6 * KZV_DECODE_FUSED_MAX_LAYERS + 1) return kzv_fail(KZV_E_ARG, "pack_frag_multi: 1..%d matrices", 6 * KZV_DECODE_FUSED_MAX_LAYERS + 1);
+    if (n < 1 || n > 6 * KZV_DECODE_FUSED_MAX_LAYERS + 2) return kzv_fail(KZV_E_ARG, "pack_frag_multi: 1..%d matrices", 6 * KZV_DECODE_FUSED_MAX_LAYERS + 2);
     PackTable tab;
     int total = 0;
     for (int i = 0; i < n; ++i) {
         if (jobs[i].N % 16 || jobs[i].K % 32) return kzv_fail(KZV_E_ARG, "pack_frag_multi: N %% 16, K %% 32");
-        tab.d[i] = PackDesc{(const uint4*)jobs[i].src, (uint4*)jobs[i].dst, jobs[i].N, jobs[i].K, total};
+        tab.d[i] = PackDesc{(const uint4*)jobs[i].src, (uint4*)jobs[i].dst, jobs[i].N, jobs[i].K, total, jobs[i].n_valid > 0 ? jobs[i].n_valid : jobs[i].N};
         total += jobs[i].N * jobs[i].K / 8;
     }
     tab.n = n;

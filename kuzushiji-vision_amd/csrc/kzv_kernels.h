@@ -111,5 +111,10 @@ struct KzvDecChainB {          // s2 = drop(cctx Wco^T + b) + x1; x2 = LN2(s2); 
 int kzv_dec_chain_supported(int Hd, int Fd);
 int kzv_dec_chain_a(const KzvDecChainA& a, hipStream_t s);
 int kzv_dec_chain_b(const KzvDecChainB& a, hipStream_t s);
-struct KzvPackJob { const bf16_t* src; bf16_t* dst; int N, K; };
+struct KzvPackJob { const bf16_t* src; bf16_t* dst; int N, K; int n_valid = 0; };      // rows >= n_valid (> 0) pack as zeros
+// LM head + cross-entropy in one launch (decoder_chain.hip): x = the head's LayerNorm output [M, 256] bf16, wp = the tied weight in
+// fragment order (ceil(V / 256) * 256 rows, zeros beyond V), labels int64 [B, L] (row m = b * T + t scores labels[b][t + 1]), count = the
+// number of scored rows (device), loss accumulated (+=), dlogits bf16 [M, Vp] or null
+struct KzvHeadCE { const bf16_t* x; const bf16_t* wp; const float* bias; const int64_t* labels; const float* count; float* loss; bf16_t* dlogits; int M, L, T, V, Vp, pad; };
+int kzv_head_ce(const KzvHeadCE& a, hipStream_t s);
 int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s);       // [N, K] row-major copies -> fragment order, one launch

@@ -86,7 +86,7 @@ struct kzv_model {
     // cross-attention K/V re-laid out for the generation steps ([layer][K|V][image][head][key][64]); rebuilt when the encoder ran
     bf16_t* ckv_dec = nullptr; size_t ckv_dec_bytes = 0; bool ckv_dec_ok = false;
     // the decoder's bf16 weights in MFMA fragment order (decode_fused.hip), refreshed after every weight change
-    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false;
+    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false; int64_t head_pack_off = 0;
     // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
     int* d_t = nullptr;
     hipGraphExec_t dgraph[3] = {nullptr, nullptr, nullptr};          // one per row table in use: none, rowtab[0], rowtab[1]
@@ -337,6 +337,11 @@ int dec_chain_mode() {
 }
 bool dec_pack_wanted(const kzv_model* m);
 int ensure_dec_pack(kzv_model* m, hipStream_t s);
+int g_head_ce = -1;
+bool head_ce_mode() {       // the one-launch LM head + CE (KZV_HEAD_CE / kzv_set_head_ce; default on)
+    if (g_head_ce < 0) { const char* e = getenv("KZV_HEAD_CE"); g_head_ce = e ? (atoi(e) != 0) : 1; }
+    return g_head_ce != 0;
+}
 
 #define KZV_TRY(expr) do { int rc__ = (expr); if (rc__ != KZV_OK) return rc__; } while (0)
 
@@ -521,8 +526,10 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     // ---- decoder layers (post-LN; HF modeling_roberta.py:421-464) -------------------------------------------
     const float* x = m->xd0; const bf16_t* xh = m->xd0h;
     // the linear chains between the attentions as two launches per layer (decoder_chain.hip) where the geometry is the reference's
-    const bool chain = dec_chain_mode() && dec_pack_wanted(m) && kzv_dec_chain_supported(Hd, Fd);
-    if (chain) KZV_TRY(ensure_dec_pack(m, s));
+    const bool packable = dec_pack_wanted(m) && kzv_dec_chain_supported(Hd, Fd);
+    const bool chain = dec_chain_mode() && packable;
+    const bool fused_head = head_ce_mode() && packable && !d_logits;      // LM head + CE in one launch (below)
+    if (chain || fused_head) KZV_TRY(ensure_dec_pack(m, s));
     const int64_t HH = (int64_t)Hd * Hd, FH = (int64_t)Fd * Hd, per = 6 * HH + 2 * FH;
     for (int i = 0; i < m->Ld; ++i) {
         DecAct& a = m->da[i];
@@ -566,8 +573,15 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     // ---- LM head (HF modeling_roberta.py:877-893; decoder.weight tied to word embeddings :684-687) + CE --------
     KZV_TRY(gemm(xh, Hd, m->w_hd, false, Md, Hd, Hd, Hd, P + m->hd_b, m->hd_gelu, Hd, KZV_EPI_GELU_F32, s, nullptr, m->hd_pre, Hd));
     KZV_TRY(kzv_ln_fwd_ex(m->hd_gelu, P + m->hln_w, P + m->hln_b, m->hd_ln, nullptr, m->hd_st, Md, Hd, eps, 1, 0, 0.f, 0, s));
-    KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, Md, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
-    KZV_TRY(kzv_ce_fwd_bwd(m->logits, m->Vp, labels, m->L, B, T, m->V, c.pad_id, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, s));
+    // no logits asked for (the training / validation step): head GEMM + log-softmax + NLL + dlogits in ONE launch, the [B*T, Vp] fp32
+    // logits never written (decoder_chain.hip head_ce_kernel).  Otherwise the GEMM materialises them and ce_kernel follows.
+    if (fused_head) {
+        KzvHeadCE hc{m->hd_ln, m->dec_pack + m->head_pack_off, P + m->hbias, labels, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, Md, m->L, T, m->V, (int)m->Vp, c.pad_id};
+        KZV_TRY(kzv_head_ce(hc, s));
+    } else {
+        KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, Md, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
+        KZV_TRY(kzv_ce_fwd_bwd(m->logits, m->Vp, labels, m->L, B, T, m->V, c.pad_id, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, s));
+    }
     if (d_loss && hipMemcpyAsync(d_loss, m->loss_acc, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return kzv_fail(KZV_E_HIP, "forward: loss copy");
     if (d_logits && logits_pos < 0) {
@@ -1057,6 +1071,11 @@ extern "C" int kzv_set_dec_chain(int on) {
     g_dec_chain = on;
     return KZV_OK;
 }
+extern "C" int kzv_set_head_ce(int on) {
+    if (on < -1 || on > 1) return kzv_fail(KZV_E_ARG, "set_head_ce: -1 (environment default), 0 or 1");
+    g_head_ce = on;
+    return KZV_OK;
+}
 extern "C" int kzv_set_decode_one_launch(int on) {
     if (on < -1 || on > 1) return kzv_fail(KZV_E_ARG, "set_decode_one_launch: -1 (environment default), 0 or 1");
     g_decode_one_launch = on;
@@ -1075,8 +1094,10 @@ bool dec_pack_wanted(const kzv_model* m) {
 int ensure_dec_pack(kzv_model* m, hipStream_t s) {
     if (m->dec_pack_ok || !dec_pack_wanted(m)) return KZV_OK;
     const int64_t Hd = m->Hd, Fd = m->Fd, per = 3 * Hd * Hd + 3 * Hd * Hd + 2 * Fd * Hd;
+    const int64_t vq = (m->V + 255) / 256 * 256;                 // the tied LM-head weight in 256-row chunks, zero rows beyond the vocabulary (head_ce_kernel)
+    m->head_pack_off = per * m->Ld + Hd * Hd;
     if (!m->dec_pack) {
-        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(per * m->Ld + Hd * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
+        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(per * m->Ld + Hd * Hd + vq * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
         for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
     }
     std::vector<KzvPackJob> jobs;
@@ -1090,6 +1111,7 @@ int ensure_dec_pack(kzv_model* m, hipStream_t s) {
         jobs.push_back({m->w_dfc2[i].w, o, (int)Hd, (int)Fd});
     }
     jobs.push_back({m->w_hd.w, m->dec_pack + per * m->Ld, (int)Hd, (int)Hd});
+    jobs.push_back({m->w_word.w, m->dec_pack + m->head_pack_off, (int)vq, (int)Hd, m->V});
     KZV_TRY(kzv_pack_frag_multi(jobs.data(), (int)jobs.size(), s));
     m->dec_pack_ok = true;
     return KZV_OK;

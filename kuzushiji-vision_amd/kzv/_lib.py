@@ -169,6 +169,7 @@ SYMBOLS = {
     "kzv_decode_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kzv_set_decode_one_launch": (C.c_int, [C.c_int]),
     "kzv_set_dec_chain": (C.c_int, [C.c_int]),
+    "kzv_set_head_ce": (C.c_int, [C.c_int]),
     "kzv_decode_step_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "kzv_decode_reorder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "kzv_decode_prep": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 def _default_mode_afterwards():
     yield
     L.load().kzv_set_dec_chain(-1)
+    L.load().kzv_set_head_ce(-1)
 
 
 def _run(cfg, tmp_path, B, Lh, train, seed):
@@ -55,6 +56,39 @@ def test_chains_equal_the_launch_per_operation_forward(tmp_path, B, Lh, train):
         dg = float((g0 - g1).abs().max()); sc = float(g0.abs().max())
         print(f", largest gradient difference {dg:.2e} of {sc:.2e}")
         assert dg < 1e-4 * sc                                   # same arithmetic, same dropout bits: differences are summation order at most
+
+
+@pytest.mark.parametrize("B,Lh,train,vocab", [(5, 30, True, 4300), (3, 12, True, 100), (7, 23, False, 777), (70, 9, True, 4300)])
+def test_one_launch_lm_head_and_cross_entropy_equals_gemm_plus_ce_kernel(tmp_path, B, Lh, train, vocab):
+    """kzv_set_head_ce(1) (default): lm_head.decoder + log-softmax + NLL + dlogits in one launch, logits never written (SURVEY K9;
+    csrc/decoder_chain.hip head_ce_kernel) against the head GEMM + ce_kernel it replaces -- same model, batch and dropout seed: the loss
+    and EVERY gradient (the head's two gradient GEMMs read the bf16 dlogits the kernel wrote).  Vocabularies that end inside a
+    256-column chunk and inside a 64-column pad (100 -> Vp 128, 777 -> 832), rows past M in the last workgroup, ignored (pad) targets,
+    and the validation form (no gradient buffer)."""
+    cfg = dataclasses.replace(tiny_config(), dec_hidden=256, dec_heads=4, dec_ffn=768, dec_layers=2, vocab=vocab)
+    lib = L.load()
+    d = build_decoder_dir(str(tmp_path / "dec"), cfg)
+    m = TrOCRModel(cfg.encoder_config_dict(), d, init_seed=3 + B, load_tokenizer=False)
+    px, lab = synthetic_batch(cfg, B, Lh, seed=5 + B, min_chars=1, max_chars=Lh - 2)
+    pxt, ids = torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()
+    out = []
+    for mode in (0, 1):
+        L.check(lib.kzv_set_head_ce(mode), "mode")
+        m.train() if train else m.eval()
+        m.zero_grad()
+        loss, _ = m.forward_loss(pxt, ids, want_logits=False, seed=13)
+        grads = None
+        if train:
+            m.backward()
+            grads = m.flat_grads.clone()
+        torch.cuda.synchronize()
+        out.append((float(loss), grads))
+    (l0, g0), (l1, g1) = out
+    assert np.isfinite(l1) and abs(l0 - l1) < 2e-6 * max(1.0, abs(l0)), (l0, l1)
+    if train:
+        dg = float((g0 - g1).abs().max()); sc = float(g0.abs().max())
+        print(f"B={B} L={Lh} V={vocab}: loss {l0:.6f} / {l1:.6f}, largest gradient difference {dg:.2e} of {sc:.2e}")
+        assert dg < 2e-3 * sc        # dlogits are bf16 on both sides: an fp32 summation-order difference of a logit moves single entries by one bf16 ulp
 
 
 def test_chains_at_the_benchmark_decoder_geometry(tmp_path):
