@@ -78,6 +78,11 @@ __device__ long long g_chain_stamps[32];
 #endif
 
 struct Drop { unsigned thr16; float inv_keep; unsigned key; };
+// The residual operand of a "dropout(linear) + residual" epilogue: a stored fp32 tensor x, or -- when x is null -- the LayerNorm output
+// it would hold, recomputed from that LayerNorm's INPUT sum s, its row statistics st = (mean, rstd) and its weights (the arithmetic of
+// ln_rows / ln_fwd_kernel, so the same bits): the fp32 LayerNorm outputs of a decoder layer are read by nothing but the next residual,
+// so the chains do not write them (3 x 15.7 MB per layer at 15k rows).
+struct Resid { const float* x; const float* s; const float* st; const float* g; const float* b; };
 
 // 64 rows x 256 bf16 columns, global -> LDS (rows past M read as zeros)
 __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, bf16_t* dst, int m0, int M, int tid) {
@@ -94,7 +99,7 @@ __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, bf16_t
 // global memory from the MFMA layout -- a lane holds 4 columns of 16 different rows there, i.e. 32- / 64-byte pieces of 16 rows per
 // store instruction, which is what made the first version of these kernels 2.7x slower than its byte count: every tensor leaves
 // through an LDS tile as whole rows.)
-__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const float* __restrict__ resid, const Drop& d,
+__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const Resid& resid, const Drop& d,
                                                float* s_lds, int m0, int M, int w, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -112,7 +117,14 @@ __device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const 
                     v[0] *= drop_keep(b0, 0, d.thr16, d.inv_keep); v[1] *= drop_keep(b0, 1, d.thr16, d.inv_keep);
                     v[2] *= drop_keep(b1, 0, d.thr16, d.inv_keep); v[3] *= drop_keep(b1, 1, d.thr16, d.inv_keep);
                 }
-                const float4 x4 = *(const float4*)(resid + (int64_t)m * HD + n0);
+                float4 x4;
+                if (resid.x) x4 = *(const float4*)(resid.x + (int64_t)m * HD + n0);
+                else {
+                    const float4 sv = *(const float4*)(resid.s + (int64_t)m * HD + n0), gm = *(const float4*)(resid.g + n0), bt = *(const float4*)(resid.b + n0);
+                    const float mean = resid.st[2 * (int64_t)m], rstd = resid.st[2 * (int64_t)m + 1];
+                    const float a0 = sv.x - mean, a1 = sv.y - mean, a2 = sv.z - mean, a3 = sv.w - mean;
+                    x4 = make_float4(a0 * rstd * gm.x + bt.x, a1 * rstd * gm.y + bt.y, a2 * rstd * gm.z + bt.z, a3 * rstd * gm.w + bt.w);
+                }
                 *(float4*)(s_lds + row * LDS_ + n0) = make_float4(v[0] + x4.x, v[1] + x4.y, v[2] + x4.z, v[3] + x4.w);
             }
         }
@@ -138,7 +150,7 @@ __device__ __forceinline__ void ln_rows(const float* s_lds, const float* __restr
         if (lane == 0) { stats[2 * (int64_t)m] = mean; stats[2 * (int64_t)m + 1] = rstd; }
         const float o0 = a * rstd * gm.x + bt.x, o1 = b * rstd * gm.y + bt.y, o2 = c * rstd * gm.z + bt.z, o3 = d * rstd * gm.w + bt.w;
         const uint2 h = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
-        *(float4*)(x_out + (int64_t)m * HD + lane * 4) = make_float4(o0, o1, o2, o3);
+        if (x_out) *(float4*)(x_out + (int64_t)m * HD + lane * 4) = make_float4(o0, o1, o2, o3);
         *(uint2*)(xh_out + (int64_t)m * HD + lane * 4) = h;
         *(uint2*)(a_lds + row * LDH + lane * 4) = h;
     }
@@ -167,11 +179,11 @@ __device__ __forceinline__ void rows_out(const bf16_t* t, int ldt, bf16_t* __res
 }
 
 struct SegA {
-    const bf16_t* ctx; const float* xres; const bf16_t* wo; const float* bo; Drop drop; const float *g1, *b1; const bf16_t* wcq; const float* bcq;
+    const bf16_t* ctx; Resid xres; const bf16_t* wo; const float* bo; Drop drop; const float *g1, *b1; const bf16_t* wcq; const float* bcq;
     float* s1; float* st1; float* x1; bf16_t* x1h; bf16_t* cq; int M; float eps;
 };
 struct SegB {
-    const bf16_t* cctx; const float* x1; const bf16_t* wco; const float* bco; Drop drop3; const float *g2, *b2;
+    const bf16_t* cctx; Resid x1; const bf16_t* wco; const float* bco; Drop drop3; const float *g2, *b2;
     const bf16_t* wfc1; const float* bfc1; const bf16_t* wfc2; const float* bfc2; Drop drop4; const float *g3, *b3;
     const bf16_t* wqkv; const float* bqkv;                       // the next layer's QKV projection, or null
     float *s2, *st2, *x2; bf16_t* x2h; bf16_t *pre, *act; float *s3, *st3, *x3; bf16_t* x3h; bf16_t* qkv;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     }
     wg_barrier();                // every wave has read the activation tile: the sum tile (same memory) may be written
     CH_STAMP(7);
-    resid_epilogue(acc3, p.bfc2, p.x2, p.drop4, ssum, m0, p.M, w, opaque(lane0));
+    resid_epilogue(acc3, p.bfc2, Resid{p.x2, p.s2, p.st2, p.g2, p.b2}, p.drop4, ssum, m0, p.M, w, opaque(lane0));      // x2: this workgroup's own rows, written above
     wg_barrier();
     CH_STAMP(8);
     ln_rows(ssum, p.g3, p.b3, p.eps, p.s3, p.x3, p.x3h, p.st3, a1, m0, p.M, w, opaque(lane0));
@@ -466,7 +478,7 @@ int kzv_dec_chain_supported(int Hd, int Fd) { return Hd == HD && Fd == FD; }
 int kzv_dec_chain_a(const KzvDecChainA& a, hipStream_t s) {
     if (a.M < 1) return kzv_fail(KZV_E_ARG, "dec_chain_a: rows");
     SegA p;
-    p.ctx = a.ctx; p.xres = a.xres; p.wo = a.wo; p.bo = a.bo; p.g1 = a.g1; p.b1 = a.b1; p.wcq = a.wcq; p.bcq = a.bcq;
+    p.ctx = a.ctx; p.xres = Resid{a.xres, a.xres_s, a.xres_st, a.xres_g, a.xres_b}; p.wo = a.wo; p.bo = a.bo; p.g1 = a.g1; p.b1 = a.b1; p.wcq = a.wcq; p.bcq = a.bcq;
     p.s1 = a.s1; p.st1 = a.st1; p.x1 = a.x1; p.x1h = a.x1h; p.cq = a.cq; p.M = a.M; p.eps = a.eps;
     p.drop.key = a.drop_key; kzv_drop_params(a.drop_p, &p.drop.thr16, &p.drop.inv_keep);
     static bool attr_done = false;
@@ -480,7 +492,7 @@ int kzv_dec_chain_b(const KzvDecChainB& a, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)dec_chain_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B); attr_done = true; }
     SegB p;
-    p.cctx = a.cctx; p.x1 = a.x1; p.wco = a.wco; p.bco = a.bco; p.g2 = a.g2; p.b2 = a.b2; p.wfc1 = a.wfc1; p.bfc1 = a.bfc1; p.wfc2 = a.wfc2; p.bfc2 = a.bfc2;
+    p.cctx = a.cctx; p.x1 = Resid{a.x1, a.s1, a.st1, a.g1, a.b1}; p.wco = a.wco; p.bco = a.bco; p.g2 = a.g2; p.b2 = a.b2; p.wfc1 = a.wfc1; p.bfc1 = a.bfc1; p.wfc2 = a.wfc2; p.bfc2 = a.bfc2;
     p.g3 = a.g3; p.b3 = a.b3; p.wqkv = a.wqkv; p.bqkv = a.bqkv;
     p.s2 = a.s2; p.st2 = a.st2; p.x2 = a.x2; p.x2h = a.x2h; p.pre = a.pre; p.act = a.act; p.s3 = a.s3; p.st3 = a.st3; p.x3 = a.x3; p.x3h = a.x3h; p.qkv = a.qkv;
     p.M = a.M; p.eps = a.eps;

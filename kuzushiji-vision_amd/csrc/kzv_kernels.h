@@ -101,12 +101,17 @@ struct KzvDecChainA {          // s1 = drop(ctx Wo^T + b) + xres;  x1 = LN1(s1);
     const bf16_t* ctx; const float* xres; const bf16_t* wo; const float* bo; float drop_p; uint32_t drop_key; const float *g1, *b1;
     const bf16_t* wcq; const float* bcq;
     float *s1, *st1, *x1; bf16_t* x1h; bf16_t* cq; int M; float eps;
+    // xres == null: the residual is the PREVIOUS layer's x3 = LN3(s3), recomputed from its sum, statistics and weights; x1 may be null
+    // (not written: chain B recomputes it the same way)
+    const float *xres_s = nullptr, *xres_st = nullptr, *xres_g = nullptr, *xres_b = nullptr;
 };
 struct KzvDecChainB {          // s2 = drop(cctx Wco^T + b) + x1; x2 = LN2(s2); act = gelu(x2 Wfc1^T + b); s3 = drop(act Wfc2^T + b) + x2; x3 = LN3(s3); [next qkv]
     const bf16_t* cctx; const float* x1; const bf16_t* wco; const float* bco; float drop_p; uint32_t drop3_key, drop4_key; const float *g2, *b2;
     const bf16_t* wfc1; const float* bfc1; const bf16_t* wfc2; const float* bfc2; const float *g3, *b3;
     const bf16_t* wqkv; const float* bqkv;
     float *s2, *st2, *x2; bf16_t* x2h; bf16_t *pre, *act; float *s3, *st3, *x3; bf16_t* x3h; bf16_t* qkv; int M; float eps;
+    // x1 == null: recomputed from (s1, st1, g1, b1); x2 / x3 may be null (not written)
+    const float *s1 = nullptr, *st1 = nullptr, *g1 = nullptr, *b1 = nullptr;
 };
 int kzv_dec_chain_supported(int Hd, int Fd);
 int kzv_dec_chain_a(const KzvDecChainA& a, hipStream_t s);

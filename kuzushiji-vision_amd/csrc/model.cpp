@@ -540,8 +540,11 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
                      c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
         if (chain) {
             const bf16_t* wp = m->dec_pack + per * i;
-            KzvDecChainA ca{a.ctx, x, wp + 3 * HH, P + d.ob, dp(m, c.dec_hidden_dropout), key(m, site + 1), P + d.ln1w, P + d.ln1b, wp + 4 * HH, P + d.cqb,
-                            a.s1, a.st1, a.x1, a.x1h, a.cq, Md, eps};
+            // the fp32 LayerNorm outputs x1 / x2 / x3 feed nothing but the next residual add: the chains recompute them from the sums and
+            // row statistics the backward needs anyway instead of writing and re-reading them (layer 0 adds the embedding output xd0)
+            KzvDecChainA ca{a.ctx, i == 0 ? x : nullptr, wp + 3 * HH, P + d.ob, dp(m, c.dec_hidden_dropout), key(m, site + 1), P + d.ln1w, P + d.ln1b, wp + 4 * HH, P + d.cqb,
+                            a.s1, a.st1, nullptr, a.x1h, a.cq, Md, eps};
+            if (i > 0) { const DecAct& pa = m->da[i - 1]; const DecLayerP& pd = m->dp[i - 1]; ca.xres_s = pa.s3; ca.xres_st = pa.st3; ca.xres_g = P + pd.ln3w; ca.xres_b = P + pd.ln3b; }
             KZV_TRY(kzv_dec_chain_a(ca, s));
         } else {
             KZV_TRY(gemm(a.ctx, Hd, m->w_do[i], false, Md, Hd, Hd, Hd, P + d.ob, a.s1, Hd, KZV_EPI_RESID, s, x, nullptr, 0,
@@ -554,10 +557,11 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
         if (chain) {
             const bf16_t* wp = m->dec_pack + per * i;
             const bool more = i + 1 < m->Ld;
-            KzvDecChainB cb{a.cctx, a.x1, wp + 5 * HH, P + d.cob, dp(m, c.dec_hidden_dropout), key(m, site + 3), key(m, site + 4), P + d.ln2w, P + d.ln2b,
+            KzvDecChainB cb{a.cctx, nullptr, wp + 5 * HH, P + d.cob, dp(m, c.dec_hidden_dropout), key(m, site + 3), key(m, site + 4), P + d.ln2w, P + d.ln2b,
                             wp + 6 * HH, P + d.fc1b, wp + 6 * HH + FH, P + d.fc2b, P + d.ln3w, P + d.ln3b,
                             more ? m->dec_pack + per * (i + 1) : nullptr, more ? P + m->dp[i + 1].qkvb : nullptr,
-                            a.s2, a.st2, a.x2, a.x2h, a.pre, a.act, a.s3, a.st3, a.x3, a.x3h, more ? m->da[i + 1].qkv : nullptr, Md, eps};
+                            a.s2, a.st2, nullptr, a.x2h, a.pre, a.act, a.s3, a.st3, nullptr, a.x3h, more ? m->da[i + 1].qkv : nullptr, Md, eps};
+            cb.s1 = a.s1; cb.st1 = a.st1; cb.g1 = P + d.ln1w; cb.b1 = P + d.ln1b;
             KZV_TRY(kzv_dec_chain_b(cb, s));
         } else {
             KZV_TRY(gemm(a.cctx, Hd, m->w_dco[i], false, Md, Hd, Hd, Hd, P + d.cob, a.s2, Hd, KZV_EPI_RESID, s, a.x1, nullptr, 0,
