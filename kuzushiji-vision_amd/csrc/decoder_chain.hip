@@ -450,9 +450,89 @@ __global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
     }
 }
 
+// ---- the decoder's input-gradient GEMMs on the same row-panel scheme (round 4; VERDICT r03 item 5, first half) --------------------
+// dX[M, N] = dY[M, K] . W[K-out, N-in] for the six nn.Linear of a RobertaLayer (HF modeling_roberta.py:421-464) and the head's dense
+// layer, B operand = the transposed weight copy in fragment order (a second set of packs, refreshed with the first).  At ~15k rows
+// each of these was a 16 - 22 us launch of the 128 x 128 kernel at 7 % MFMA utilisation; one workgroup per 64 rows streams the
+// weights from L2 through chain_gemm's window and leaves through an LDS tile as whole rows.  Epilogues: bf16 store; fp32 store of
+// (acc + residual gradient) -- the "RESID" input-gradient form, residual optional; bf16 store of acc * gelu'(pre-activation) (DGELU).
+// The weight gradients stay the grouped gemm_tn launch; the LayerNorm backward between the GEMMs stays its own kernel.
+enum { DL_BF16 = 0, DL_RESID = 1, DL_DGELU = 2 };
+struct DecLin { const bf16_t* a; const bf16_t* wp; void* out; const float* resid; const bf16_t* aux; int M; };
+template <int CB, int KS, int EPI>
+__global__ __launch_bounds__(512) void dec_lin_kernel(const DecLin p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = KS * 32, N = CB * 128, LDA = K + 8, LDO16 = N + 8, LDO32 = N + 4;
+    bf16_t* at = (bf16_t*)smem;                                   // [RM][LDA] operand rows; the output tile aliases it after the GEMM
+    const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * RM;
+    bf16x8 R[WIN];
+    fill_window<CB, KS>(R, wave_frags<CB, KS>(p.wp, w), opaque(lane0));
+    {
+        const int t2 = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < RM * (K / 8) / 512; ++q) {
+            const int idx = t2 + q * 512, row = idx / (K / 8), ch = idx - row * (K / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + row < p.M) v = *(const uint4*)(p.a + (int64_t)(m0 + row) * K + ch * 8);
+            *(uint4*)(at + row * LDA + ch * 8) = v;
+        }
+    }
+    wg_barrier();
+    const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
+    f32x4 acc[CB][RT];
+    chain_gemm<CB, KS, CB, KS>(R, wave_frags<CB, KS>(p.wp, w), nullptr, at, LDA, lane, acc);
+    wg_barrier();                                                 // every wave has read the operand tile: it becomes the output tile
+    if constexpr (EPI == DL_RESID) {
+        float* ot = (float*)smem;                                 // [RM][LDO32] fp32
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int n0 = (w + 8 * c) * 16 + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) *(f32x4*)(ot + (rt * 16 + l15) * LDO32 + n0) = acc[c][rt];
+        }
+        wg_barrier();
+        const int t2 = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < RM * (N / 4) / 512; ++q) {
+            const int idx = t2 + q * 512, row = idx / (N / 4), ch = idx - row * (N / 4);
+            if (m0 + row < p.M) {
+                float4 v = *(const float4*)(ot + row * LDO32 + ch * 4);
+                if (p.resid) { const float4 r = *(const float4*)(p.resid + (int64_t)(m0 + row) * N + ch * 4); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                *(float4*)((float*)p.out + (int64_t)(m0 + row) * N + ch * 4) = v;
+            }
+        }
+    } else {
+        bf16_t* ot = (bf16_t*)smem;                               // [RM][LDO16] bf16
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int n0 = (w + 8 * c) * 16 + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 v = acc[c][rt];
+                if constexpr (EPI == DL_DGELU) {                  // the forward's saved gelu'(pre-activation), as nt_emit<KZV_EPI_DGELU>
+                    const int m = m0 + rt * 16 + l15;
+                    uint2 u = make_uint2(0, 0);
+                    if (m < p.M) u = *(const uint2*)(p.aux + (int64_t)m * N + n0);
+                    v[0] *= bf2f((bf16_t)(u.x & 0xffff)); v[1] *= bf2f((bf16_t)(u.x >> 16)); v[2] *= bf2f((bf16_t)(u.y & 0xffff)); v[3] *= bf2f((bf16_t)(u.y >> 16));
+                }
+                *(uint2*)(ot + (rt * 16 + l15) * LDO16 + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+        }
+        wg_barrier();
+        const int t2 = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < RM * (N / 8) / 512; ++q) {
+            const int idx = t2 + q * 512, row = idx / (N / 8), ch = idx - row * (N / 8);
+            if (m0 + row < p.M) *(uint4*)((bf16_t*)p.out + (int64_t)(m0 + row) * N + ch * 8) = *(const uint4*)(ot + row * LDO16 + ch * 8);
+        }
+    }
+}
+
 // every decoder weight of the model -> fragment order, one launch
 struct PackDesc { const uint4* src; uint4* dst; int N, K, t0, n_valid; };
-struct PackTable { PackDesc d[6 * KZV_DECODE_FUSED_MAX_LAYERS + 2]; int n; };
+constexpr int PACK_PER_LAUNCH = 96;        // 32-byte descriptors in the kernel argument block (4 KiB limit)
+struct PackTable { PackDesc d[PACK_PER_LAUNCH]; int n; };
 __global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
@@ -502,6 +582,27 @@ int kzv_dec_chain_b(const KzvDecChainB& a, hipStream_t s) {
     return kzv_check_launch("dec_chain_b");
 }
 
+// N / K: output / reduction width (256 or 768, not both 768); epi: 0 bf16, 1 fp32 (+ resid), 2 bf16 * aux
+int kzv_dec_lin(const bf16_t* a, const bf16_t* wp, void* out, const float* resid, const bf16_t* aux, int M, int N, int K, int epi, hipStream_t s) {
+    if (!a || !wp || !out || M < 1 || (epi == DL_DGELU && !aux)) return kzv_fail(KZV_E_ARG, "dec_lin: bad argument");
+    DecLin p{a, wp, out, resid, aux, M};
+    const dim3 grid((M + RM - 1) / RM);
+#define KZV_DL(CB_, KS_, E_)                                                                                         \
+    do {                                                                                                             \
+        constexpr int lds = RM * ((KS_ * 32 + 8) * 2 > (E_ == DL_RESID ? (CB_ * 128 + 4) * 4 : (CB_ * 128 + 8) * 2) ? (KS_ * 32 + 8) * 2 : (E_ == DL_RESID ? (CB_ * 128 + 4) * 4 : (CB_ * 128 + 8) * 2)); \
+        static bool attr_done = false;                                                                               \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)dec_lin_kernel<CB_, KS_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
+        hipLaunchKernelGGL((dec_lin_kernel<CB_, KS_, E_>), grid, dim3(512), lds, s, p);                              \
+        return kzv_check_launch("dec_lin");                                                                          \
+    } while (0)
+    if (N == 256 && K == 256 && epi == DL_BF16) KZV_DL(2, 8, DL_BF16);
+    if (N == 256 && K == 256 && epi == DL_RESID) KZV_DL(2, 8, DL_RESID);
+    if (N == 256 && K == 768 && epi == DL_RESID) KZV_DL(2, 24, DL_RESID);
+    if (N == 768 && K == 256 && epi == DL_DGELU) KZV_DL(6, 8, DL_DGELU);
+#undef KZV_DL
+    return kzv_fail(KZV_E_ARG, "dec_lin: no instance for N %d, K %d, epilogue %d", N, K, epi);
+}
+
 int kzv_head_ce(const KzvHeadCE& a, hipStream_t s) {
     if (!a.x || !a.wp || !a.bias || !a.labels || !a.count || !a.loss || a.M < 1 || a.V < 1 || a.Vp % 8 || a.Vp < a.V) return kzv_fail(KZV_E_ARG, "head_ce: bad argument");
     HeadCE p;
@@ -515,15 +616,19 @@ int kzv_head_ce(const KzvHeadCE& a, hipStream_t s) {
 }
 
 int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s) {
-    if (n < 1 || n > 6 * KZV_DECODE_FUSED_MAX_LAYERS + 2) return kzv_fail(KZV_E_ARG, "pack_frag_multi: 1..%d matrices", 6 * KZV_DECODE_FUSED_MAX_LAYERS + 2);
-    PackTable tab;
-    int total = 0;
-    for (int i = 0; i < n; ++i) {
-        if (jobs[i].N % 16 || jobs[i].K % 32) return kzv_fail(KZV_E_ARG, "pack_frag_multi: N %% 16, K %% 32");
-        tab.d[i] = PackDesc{(const uint4*)jobs[i].src, (uint4*)jobs[i].dst, jobs[i].N, jobs[i].K, total, jobs[i].n_valid > 0 ? jobs[i].n_valid : jobs[i].N};
-        total += jobs[i].N * jobs[i].K / 8;
+    if (n < 1 || n > KZV_PACK_MAX_JOBS) return kzv_fail(KZV_E_ARG, "pack_frag_multi: 1..%d matrices", KZV_PACK_MAX_JOBS);
+    for (int j0 = 0; j0 < n; j0 += PACK_PER_LAUNCH) {
+        PackTable tab;
+        int total = 0;
+        const int cnt = n - j0 < PACK_PER_LAUNCH ? n - j0 : PACK_PER_LAUNCH;
+        for (int i = 0; i < cnt; ++i) {
+            const KzvPackJob& jb = jobs[j0 + i];
+            if (jb.N % 16 || jb.K % 32) return kzv_fail(KZV_E_ARG, "pack_frag_multi: N %% 16, K %% 32");
+            tab.d[i] = PackDesc{(const uint4*)jb.src, (uint4*)jb.dst, jb.N, jb.K, total, jb.n_valid > 0 ? jb.n_valid : jb.N};
+            total += jb.N * jb.K / 8;
+        }
+        tab.n = cnt;
+        hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tab, total);
     }
-    tab.n = n;
-    hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((total + 255) / 256), dim3(256), 0, s, tab, total);
     return kzv_check_launch("pack_frag_multi");
 }

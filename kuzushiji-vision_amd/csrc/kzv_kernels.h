@@ -122,4 +122,7 @@ struct KzvPackJob { const bf16_t* src; bf16_t* dst; int N, K; int n_valid = 0; }
 // number of scored rows (device), loss accumulated (+=), dlogits bf16 [M, Vp] or null
 struct KzvHeadCE { const bf16_t* x; const bf16_t* wp; const float* bias; const int64_t* labels; const float* count; float* loss; bf16_t* dlogits; int M, L, T, V, Vp, pad; };
 int kzv_head_ce(const KzvHeadCE& a, hipStream_t s);
+#define KZV_PACK_MAX_JOBS (12 * KZV_DECODE_FUSED_MAX_LAYERS + 4)
+// one input-gradient GEMM of the decoder on the row-panel scheme (decoder_chain.hip): out[M, N] = a[M, K] . (packed W^T)  [+ resid | * aux]
+int kzv_dec_lin(const bf16_t* a, const bf16_t* wp, void* out, const float* resid, const bf16_t* aux, int M, int N, int K, int epi, hipStream_t s);
 int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s);       // [N, K] row-major copies -> fragment order, one launch

@@ -86,7 +86,7 @@ struct kzv_model {
     // cross-attention K/V re-laid out for the generation steps ([layer][K|V][image][head][key][64]); rebuilt when the encoder ran
     bf16_t* ckv_dec = nullptr; size_t ckv_dec_bytes = 0; bool ckv_dec_ok = false;
     // the decoder's bf16 weights in MFMA fragment order (decode_fused.hip), refreshed after every weight change
-    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false; int64_t head_pack_off = 0;
+    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false; int64_t head_pack_off = 0, tpack_off = 0;
     // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
     int* d_t = nullptr;
     hipGraphExec_t dgraph[3] = {nullptr, nullptr, nullptr};          // one per row table in use: none, rowtab[0], rowtab[1]
@@ -610,6 +610,17 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     float* P = m->P; float* G = m->G;
     const int CK = m->Ld * 2 * Hd;
     m->wbatch.clear();
+    // the decoder's input-gradient GEMMs on the row-panel kernel (decoder_chain.hip kzv_dec_lin) where the forward's fragment-ordered
+    // packs exist (the reference decoder's geometry, chains on): transposed packs, same layout as the forward's
+    static int dgrad_rows = -1;          // dev A/B: KZV_DEC_DGRAD=0 keeps the 128 x 128 kernel for these
+    if (dgrad_rows < 0) { const char* e = getenv("KZV_DEC_DGRAD"); dgrad_rows = e ? atoi(e) : 1; }
+    const bool rows_dgrad = dgrad_rows && dec_chain_mode() && dec_pack_wanted(m) && kzv_dec_chain_supported(Hd, Fd) && m->dec_pack_ok && !m->use_side;
+    const int64_t HHd = (int64_t)Hd * Hd, FHd = (int64_t)Fd * Hd, perd = 6 * HHd + 2 * FHd;
+    // measured (profiles/r04): the 256 x 256 products take 7.8 / 12.6 us there against ~16 us on the 128 x 128 kernel; the 768-wide ones
+    // (fc2's DGELU output, the K = 768 reductions of fc1 / qkv) are SLOWER on it (35 / 21 us against 22 / 16 - 22): they keep gemm_nt
+    static int wide_rows = -1;
+    if (wide_rows < 0) { const char* e = getenv("KZV_DEC_DGRAD_WIDE"); wide_rows = e ? atoi(e) : 0; }
+    auto tp = [&](int layer, int64_t off) { return (const bf16_t*)(m->dec_pack + m->tpack_off + perd * layer + off); };
     // ---- CE -> LM head ------------------------------------------------------------------------------
     KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, G + m->hbias));
     KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
@@ -617,7 +628,8 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
     const bf16_t* x_last_h = m->Ld ? m->da[m->Ld - 1].x3h : m->xd0h;
     KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, nullptr));
-    KZV_TRY(gemm(m->dy_d, Hd, m->w_hd, true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_F32, s));
+    if (rows_dgrad) KZV_TRY(kzv_dec_lin(m->dy_d, tp(m->Ld, 0), m->dx_d, nullptr, nullptr, Md, Hd, Hd, 1, s));
+    else KZV_TRY(gemm(m->dy_d, Hd, m->w_hd, true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_F32, s));
     KZV_TRY(wgrad_flush(m, s));          // LM head (tied word embedding) + head dense: before dy_d is rewritten
     // ---- decoder layers, last to first -----------------------------------------------------------------
     for (int i = m->Ld - 1; i >= 0; --i) {
@@ -631,9 +643,11 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
                               m->dy_d, dp(m, c.dec_hidden_dropout), key(m, site + 4)));
         KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
         KZV_TRY(wait_cls(m, CLS_DBIG, s));
-        KZV_TRY(gemm(m->dy_d, Hd, m->w_dfc2[i], true, Md, Fd, Hd, Fd, nullptr, m->dbig_d, Fd, KZV_EPI_DGELU, s, nullptr, a.pre, Fd));
+        if (rows_dgrad && wide_rows) KZV_TRY(kzv_dec_lin(m->dy_d, tp(i, 6 * HHd + FHd), m->dbig_d, nullptr, a.pre, Md, Fd, Hd, 2, s));
+        else KZV_TRY(gemm(m->dy_d, Hd, m->w_dfc2[i], true, Md, Fd, Hd, Fd, nullptr, m->dbig_d, Fd, KZV_EPI_DGELU, s, nullptr, a.pre, Fd));
         KZV_TRY(wgrad_batch(m, CLS_DBIG, s, m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
-        KZV_TRY(gemm(m->dbig_d, Fd, m->w_dfc1[i], true, Md, Hd, Fd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+        if (rows_dgrad && wide_rows) KZV_TRY(kzv_dec_lin(m->dbig_d, tp(i, 6 * HHd), m->dx_d, m->dsum_d, nullptr, Md, Hd, Fd, 1, s));
+        else KZV_TRY(gemm(m->dbig_d, Fd, m->w_dfc1[i], true, Md, Hd, Fd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // cross-attention block: x2 = LN(s2), s2 = x1 + drop(o(CA(q(x1), kv(enc))))
         KZV_TRY(wait_cls(m, CLS_DY, s));
         bf16_t* dy2 = m->use_side ? m->dy_d : m->dy_d2;      // grouped launch: the three dy of a layer stay alive until its end
@@ -642,23 +656,27 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
                               dy2, dp(m, c.dec_hidden_dropout), key(m, site + 3)));
         KZV_TRY(wgrad_batch(m, CLS_DY, s, dy2, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
         KZV_TRY(wait_cls(m, CLS_MISC, s));   // dq_d (and, first layer, dlogits' reader) before the cross-attention backward rewrites dq_d
-        KZV_TRY(gemm(dy2, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
+        if (rows_dgrad) KZV_TRY(kzv_dec_lin(dy2, tp(i, 5 * HHd), m->dctx_d, nullptr, nullptr, Md, Hd, Hd, 0, s));
+        else KZV_TRY(gemm(dy2, Hd, m->w_dco[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
                      m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->npa,
                      dp(m, c.dec_attn_dropout), key(m, site + 2), s));
         KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
-        KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+        if (rows_dgrad) KZV_TRY(kzv_dec_lin(m->dq_d, tp(i, 4 * HHd), m->dx_d, m->dsum_d, nullptr, Md, Hd, Hd, 1, s));
+        else KZV_TRY(gemm(m->dq_d, Hd, m->w_dcq[i], true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         // self-attention block: x1 = LN(s1), s1 = x + drop(o(SA(qkv(x))))
         KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s1, a.st1, P + d.ln1w, m->dsum_d, 0, G + d.ln1w, G + d.ln1b, Md, Hd, 1, 0, 0.f, 0, s,
                               dy3, dp(m, c.dec_hidden_dropout), key(m, site + 1)));
         KZV_TRY(wgrad_batch(m, CLS_DY, s, dy3, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
         KZV_TRY(wait_cls(m, CLS_DQKV, s));
-        KZV_TRY(gemm(dy3, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
+        if (rows_dgrad) KZV_TRY(kzv_dec_lin(dy3, tp(i, 3 * HHd), m->dctx_d, nullptr, nullptr, Md, Hd, Hd, 0, s));
+        else KZV_TRY(gemm(dy3, Hd, m->w_do[i], true, Md, Hd, Hd, Hd, nullptr, m->dctx_d, Hd, KZV_EPI_BF16, s));
         KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
                      m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
         KZV_TRY(wgrad_batch(m, CLS_DQKV, s, m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
-        KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+        if (rows_dgrad && wide_rows) KZV_TRY(kzv_dec_lin(m->dqkv_d, tp(i, 0), m->dx_d, m->dsum_d, nullptr, Md, Hd, 3 * Hd, 1, s));
+        else KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
         KZV_TRY(wgrad_flush(m, s));      // the six weight gradients of this layer in one grid
     }
     // ---- decoder embeddings: x0 = drop(LN(word + type + pos)) ---------------------------------------------
@@ -1101,7 +1119,7 @@ int ensure_dec_pack(kzv_model* m, hipStream_t s) {
     const int64_t vq = (m->V + 255) / 256 * 256;                 // the tied LM-head weight in 256-row chunks, zero rows beyond the vocabulary (head_ce_kernel)
     m->head_pack_off = per * m->Ld + Hd * Hd;
     if (!m->dec_pack) {
-        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(per * m->Ld + Hd * Hd + vq * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
+        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(2 * (per * m->Ld + Hd * Hd) + vq * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
         for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
     }
     std::vector<KzvPackJob> jobs;
@@ -1116,6 +1134,18 @@ int ensure_dec_pack(kzv_model* m, hipStream_t s) {
     }
     jobs.push_back({m->w_hd.w, m->dec_pack + per * m->Ld, (int)Hd, (int)Hd});
     jobs.push_back({m->w_word.w, m->dec_pack + m->head_pack_off, (int)vq, (int)Hd, m->V});
+    // the TRANSPOSED copies (B operands of the input-gradient GEMMs, kzv_dec_lin): [in, out] row-major, dense because out % 64 == 0
+    m->tpack_off = m->head_pack_off + vq * Hd;
+    for (int i = 0; i < m->Ld; ++i) {
+        bf16_t* o = m->dec_pack + m->tpack_off + per * i;
+        jobs.push_back({m->w_dqkv[i].wt, o, (int)Hd, 3 * (int)Hd}); o += 3 * Hd * Hd;
+        jobs.push_back({m->w_do[i].wt, o, (int)Hd, (int)Hd}); o += Hd * Hd;
+        jobs.push_back({m->w_dcq[i].wt, o, (int)Hd, (int)Hd}); o += Hd * Hd;
+        jobs.push_back({m->w_dco[i].wt, o, (int)Hd, (int)Hd}); o += Hd * Hd;
+        jobs.push_back({m->w_dfc1[i].wt, o, (int)Hd, (int)Fd}); o += Fd * Hd;
+        jobs.push_back({m->w_dfc2[i].wt, o, (int)Fd, (int)Hd});
+    }
+    jobs.push_back({m->w_hd.wt, m->dec_pack + m->tpack_off + per * m->Ld, (int)Hd, (int)Hd});
     KZV_TRY(kzv_pack_frag_multi(jobs.data(), (int)jobs.size(), s));
     m->dec_pack_ok = true;
     return KZV_OK;
