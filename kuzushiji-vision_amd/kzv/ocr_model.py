@@ -642,6 +642,7 @@ class OCRModel:
 
     use_graph = True
     GRAPH_WARM_STEPS = 2          # eager steps of a geometry before it is captured (library workspaces reach their final size)
+    MAX_GRAPHS = 8                # captured geometries kept (each owns its activations' memory pool); further ones run launch by launch
 
     def _fit_step_graph(self, batch):
         import torch
@@ -654,7 +655,7 @@ class OCRModel:
         key = (tuple(images.shape), tuple(gt.shape), has_ctc)
         ent = self._graphs.setdefault(key, SimpleNamespace(seen=0, graph=None))
         ent.seen += 1
-        if ent.graph is None and ent.seen <= self.GRAPH_WARM_STEPS:
+        if ent.graph is None and (ent.seen <= self.GRAPH_WARM_STEPS or sum(1 for e in self._graphs.values() if e.graph is not None) >= self.MAX_GRAPHS):
             return self._fit_step_eager(batch)
         o = self._optimizer or self.configure_optimizers()
         if ent.graph is None:
