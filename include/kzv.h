@@ -385,6 +385,10 @@ int kzv_ocr_col2im(const float* dcols, float* dx, int N, int H, int W, int C, in
 int kzv_ocr_conv_weight(const float* w, void* wp_bf16, void* wpT_bf16, int Cout, int Cin, int KH, int KW, int Kp, void* stream);
 /* gradient of the packed weight fp32 [Cout, Kp] accumulated into the state_dict layout [Cout, Cin, KH, KW] */
 int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, int Cin, int KH, int KW, int Kp, void* stream);
+/* Both for n <= 40 convolutions in ONE launch each (what a ResNet34 step needs after its optimizer step / at the end of its backward):
+ * HOST arrays of n device pointers and geom[n][5] = (Cout, Cin, KH, KW, Kp). */
+int kzv_ocr_conv_weight_multi(int n, const float* const* w, void* const* wp_bf16, void* const* wpT_bf16, const int32_t* geom, void* stream);
+int kzv_ocr_conv_wgrad_unpack_multi(int n, const float* const* gp, float* const* g, const int32_t* geom, void* stream);
 /* nn.BatchNorm2d (+ the BasicBlock's residual add and ReLU): out bf16 = [relu](gamma * (y - mean) * rstd + beta [+ resid]); y fp32
  * [M, C].  train: batch statistics (biased variance), running statistics updated with `momentum` and the unbiased variance;
  * eval: the running statistics.  mean / rstd [C] are kept for the backward.  d_scratch: kzv_ocr_bn_scratch_floats(M, C) floats.

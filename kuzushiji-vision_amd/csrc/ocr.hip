@@ -149,6 +149,62 @@ __global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gp, float* __
     g[t] += gp[(int64_t)o * Kp + (kh * KW + kw) * Cin + c];
 }
 
+// every convolution of the model in ONE launch each way (a ResNet34 step repacks 36 weights after the optimizer step and unpacks 36
+// weight gradients at the end of the backward: 72 launches of ~6 us otherwise): descriptors in the kernel arguments, a block finds its
+// convolution by its first element index
+struct ConvDesc { const float* w; void* wp; void* wpT; const float* gp; float* g; int Cout, Cin, KH, KW, Kp; unsigned b0; };
+constexpr int CONV_MAX = 40, CONV_ROW_MAX = 4672;      // floats of one packed row held in LDS (ResNet34: 512 x 3 x 3 = 4608)
+struct ConvTable { ConvDesc d[CONV_MAX]; int n; };
+__device__ __forceinline__ int conv_lookup(const ConvTable& t, unsigned blk) {        // block-uniform: scalar loads from the argument block
+    int k = 0;
+    while (k + 1 < t.n && blk >= t.d[k + 1].b0) ++k;
+    return __builtin_amdgcn_readfirstlane(k);
+}
+// one block per (convolution, output channel): the channel's Cin * KH * KW weights are read as they lie (contiguous), permuted through
+// LDS into the (kh, kw, cin) column order of im2col, and written as one contiguous packed row (zero beyond KH * KW * Cin)
+template <bool F32>
+__global__ __launch_bounds__(256) void conv_weight_multi_kernel(const ConvTable t) {
+    __shared__ float row[CONV_ROW_MAX];
+    const ConvDesc d = t.d[conv_lookup(t, blockIdx.x)];
+    const int o = blockIdx.x - d.b0, KK = d.Cin * d.KH * d.KW;
+    for (int i = threadIdx.x; i < KK; i += 256) row[i] = d.w[(int64_t)o * KK + i];
+    __syncthreads();
+    for (int kk = threadIdx.x; kk < d.Kp; kk += 256) {
+        float v = 0.f;
+        if (kk < KK) { const int tap = kk / d.Cin, c = kk - tap * d.Cin; v = row[c * d.KH * d.KW + tap]; }       // tap = kh * KW + kw
+        st1<F32>(d.wp, (int64_t)o * d.Kp + kk, v);
+    }
+}
+// the transposed packed copies [Kp, Cout] from the packed ones [Cout, Kp]: 64 x 64 tiles through LDS, both sides contiguous;
+// blockIdx.x -> (convolution, tile) through the same table (b0 counts tiles here)
+template <bool F32>
+__global__ __launch_bounds__(256) void conv_weight_transpose_multi_kernel(const ConvTable t) {
+    __shared__ float tile[64][65];
+    const ConvDesc d = t.d[conv_lookup(t, blockIdx.x)];
+    const int tl = blockIdx.x - d.b0, tk = (d.Kp + 63) / 64, to = tl / tk, tkk = tl - to * tk;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int o = to * 64 + ty + 4 * i, kk = tkk * 64 + tx;
+        tile[ty + 4 * i][tx] = (o < d.Cout && kk < d.Kp) ? ld1<F32>(d.wp, (int64_t)o * d.Kp + kk) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int kk = tkk * 64 + ty + 4 * i, o = to * 64 + tx;
+        if (kk < d.Kp && o < d.Cout) st1<F32>(d.wpT, (int64_t)kk * d.Cout + o, tile[tx][ty + 4 * i]);
+    }
+}
+// the reverse for the weight gradients: one packed row in, the channel's torch-layout slice accumulated contiguously
+__global__ __launch_bounds__(256) void conv_wgrad_unpack_multi_kernel(const ConvTable t) {
+    __shared__ float row[CONV_ROW_MAX];
+    const ConvDesc d = t.d[conv_lookup(t, blockIdx.x)];
+    const int o = blockIdx.x - d.b0, KK = d.Cin * d.KH * d.KW, taps = d.KH * d.KW;
+    for (int i = threadIdx.x; i < KK; i += 256) row[i] = d.gp[(int64_t)o * d.Kp + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < KK; i += 256) { const int c = i / taps, tap = i - c * taps; d.g[(int64_t)o * KK + i] += row[tap * d.Cin + c]; }
+}
+
 // ---------------------------------------------------------------------------------------------- BatchNorm2d
 // per-channel sums over the rows of y fp32 [M, C]: pass 0 -> sum(y), pass 1 -> sum((y - mean)^2) with mean = sum0 / M.
 // One thread per (row slice, 4 channels); a block's partials meet through LDS and go to row blockIdx.x of `out` [blocks, C];
@@ -614,6 +670,39 @@ extern "C" int kzv_ocr_conv_wgrad_unpack(const float* gp, float* g, int Cout, in
     KZV_OCR_NULL(!gp || !g, "ocr_conv_wgrad_unpack: null");
     hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(nblk((int64_t)Cout * Cin * KH * KW, 256)), dim3(256), 0, (hipStream_t)stream, gp, g, Cout, Cin, KH, KW, Kp);
     return kzv_check_launch("ocr_conv_wgrad_unpack");
+}
+// the same for n convolutions at once (n <= 40; one launch): arrays of n pointers / geometries on the HOST
+extern "C" int kzv_ocr_conv_weight_multi(int n, const float* const* w, void* const* wp, void* const* wpT, const int32_t* geom /* [n][5]: Cout Cin KH KW Kp */, void* stream) {
+    KZV_OCR_NULL(n < 1 || n > CONV_MAX || !w || !wp || !wpT || !geom, "ocr_conv_weight_multi: 1..40 convolutions");
+    ConvTable t, tt; unsigned b = 0, bt = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t* g = geom + 5 * i;
+        KZV_OCR_NULL(!w[i] || !wp[i] || g[4] < g[2] * g[3] * g[1] || g[4] > CONV_ROW_MAX, "ocr_conv_weight_multi: bad entry (packed rows of <= 4672 columns)");
+        t.d[i] = ConvDesc{w[i], wp[i], wpT[i], nullptr, nullptr, g[0], g[1], g[2], g[3], g[4], b};
+        b += (unsigned)g[0];
+        tt.d[i] = t.d[i]; tt.d[i].b0 = bt;
+        if (wpT[i]) bt += (unsigned)(((g[0] + 63) / 64) * ((g[4] + 63) / 64));
+    }
+    t.n = tt.n = n;
+    KZV_OCR_LAUNCH(conv_weight_multi_kernel, dim3(b), dim3(256), (hipStream_t)stream, t);
+    bool all_t = true;
+    for (int i = 0; i < n; ++i) all_t &= wpT[i] != nullptr;
+    KZV_OCR_NULL(!all_t && bt, "ocr_conv_weight_multi: transposed copies for all convolutions or for none");
+    if (bt) KZV_OCR_LAUNCH(conv_weight_transpose_multi_kernel, dim3(bt), dim3(256), (hipStream_t)stream, tt);
+    return kzv_check_launch("ocr_conv_weight_multi");
+}
+extern "C" int kzv_ocr_conv_wgrad_unpack_multi(int n, const float* const* gp, float* const* g, const int32_t* geom, void* stream) {
+    KZV_OCR_NULL(n < 1 || n > CONV_MAX || !gp || !g || !geom, "ocr_conv_wgrad_unpack_multi: 1..40 convolutions");
+    ConvTable t; unsigned b = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t* q = geom + 5 * i;
+        KZV_OCR_NULL(!gp[i] || !g[i] || q[4] > CONV_ROW_MAX, "ocr_conv_wgrad_unpack_multi: bad entry");
+        t.d[i] = ConvDesc{nullptr, nullptr, nullptr, gp[i], g[i], q[0], q[1], q[2], q[3], q[4], b};
+        b += (unsigned)q[0];
+    }
+    t.n = n;
+    hipLaunchKernelGGL(conv_wgrad_unpack_multi_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, t);
+    return kzv_check_launch("ocr_conv_wgrad_unpack_multi");
 }
 // d_scratch: kzv_ocr_bn_scratch_floats(M, C) floats
 // rows per workgroup of the BatchNorm reductions: ~512 workgroups per launch (two rounds of the chip) between 32 and 256 rows each

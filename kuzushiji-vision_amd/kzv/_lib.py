@@ -144,6 +144,8 @@ SYMBOLS = {
     "kzv_ocr_col2im": (C.c_int, [_P, _P] + [C.c_int] * 10 + [_P]),
     "kzv_ocr_conv_weight": (C.c_int, [_P, _P, _P] + [C.c_int] * 5 + [_P]),
     "kzv_ocr_conv_wgrad_unpack": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
+    "kzv_ocr_conv_weight_multi": (C.c_int, [C.c_int, _P, _P, _P, _P, _P]),
+    "kzv_ocr_conv_wgrad_unpack_multi": (C.c_int, [C.c_int, _P, _P, _P, _P]),
     "kzv_ocr_bn_fwd": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "kzv_ocr_bn_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "kzv_ocr_bn_scratch_floats": (C.c_int64, [C.c_int64, C.c_int]),

@@ -188,9 +188,16 @@ class OCRModel:
         lib, st = self.lib, L.stream_handle()
         self._set_precision()
         for c in self.convs:
-            wp = self._w16.setdefault(c.conv_key, torch.empty(c.cout, c.Kp, dtype=self.adt, device=self.device))
-            wt = self._w16.setdefault(c.conv_key + ".T", torch.empty(c.Kp, c.cout, dtype=self.adt, device=self.device))
-            L.check(lib.kzv_ocr_conv_weight(self.param(c.conv_key + ".weight").data_ptr(), wp.data_ptr(), wt.data_ptr(), c.cout, c.cin, c.k, c.k, c.Kp, st), "conv_weight")
+            self._w16.setdefault(c.conv_key, torch.empty(c.cout, c.Kp, dtype=self.adt, device=self.device))
+            self._w16.setdefault(c.conv_key + ".T", torch.empty(c.Kp, c.cout, dtype=self.adt, device=self.device))
+        n = len(self.convs)
+        if n <= 40:                                              # every convolution's packed copies in one launch
+            t = self._conv_tables()
+            L.check(lib.kzv_ocr_conv_weight_multi(n, t.w, t.wp, t.wpT, t.geom, st), "conv_weight_multi")
+        else:
+            for c in self.convs:
+                L.check(lib.kzv_ocr_conv_weight(self.param(c.conv_key + ".weight").data_ptr(), self._w16[c.conv_key].data_ptr(), self._w16[c.conv_key + ".T"].data_ptr(),
+                                                c.cout, c.cin, c.k, c.k, c.Kp, st), "conv_weight")
         for name, (o, shp) in self.offsets.items():
             if len(shp) != 2 or "weight_hh" in name:
                 continue
@@ -225,6 +232,21 @@ class OCRModel:
 
     def __call__(self, images):
         return self.forward(images)
+
+    def _conv_tables(self):
+        """Host arrays for the one-launch forms (packed weights, packed weight gradients): built once, the buffers never move."""
+        t = getattr(self, "_ctab", None)
+        if t is None:
+            import torch
+            n = len(self.convs)
+            PA = C.c_void_p * n
+            self._gp = [torch.zeros(c.cout, c.Kp, device=self.device) for c in self.convs]           # packed weight gradients (zeroed per backward)
+            geom = (C.c_int32 * (5 * n))(*[v for c in self.convs for v in (c.cout, c.cin, c.k, c.k, c.Kp)])
+            t = self._ctab = SimpleNamespace(
+                w=PA(*[self.param(c.conv_key + ".weight").data_ptr() for c in self.convs]), wp=PA(*[self._w16[c.conv_key].data_ptr() for c in self.convs]),
+                wpT=PA(*[self._w16[c.conv_key + ".T"].data_ptr() for c in self.convs]), gp=PA(*[g.data_ptr() for g in self._gp]),
+                g=PA(*[self.grad(c.conv_key + ".weight").data_ptr() for c in self.convs]), geom=geom, index={id(c): i for i, c in enumerate(self.convs)})
+        return t
 
     def _set_precision(self):
         """The element type of the library's OCR kernels is a process-wide switch: set it before every pass of this model."""
@@ -459,6 +481,10 @@ class OCRModel:
         import torch
         lib, st, dev = self.lib, L.stream_handle(), self.device
         self._set_precision()
+        multi = len(self.convs) <= 40
+        if multi:
+            self._conv_tables()
+            torch._foreach_zero_(self._gp)
         tape, dboxes, dlogits = self._pending
         head = tape[-1][1]
         N, Hc, Wc = head["geom"]
@@ -523,6 +549,9 @@ class OCRModel:
                 L.check(lib.kzv_ocr_maxpool_bwd(da.data_ptr(), idx.data_ptr(), dpre.data_ptr(), N, H1, W1, self.stem.cout, st), "maxpool_bwd")
                 _, dy = self._bn_bwd(self.stem, k, dpre)
                 self._conv_bwd(self.stem, k, dy, need_dx=False)
+        if multi:
+            t = self._conv_tables()
+            L.check(lib.kzv_ocr_conv_wgrad_unpack_multi(len(self.convs), t.gp, t.g, t.geom, st), "wgrad_unpack_multi")
         self._pending = None
 
     def _bn_bwd(self, c: _Conv, k, da):
@@ -548,9 +577,13 @@ class OCRModel:
         lib, st, dev = self.lib, L.stream_handle(), self.device
         N, H, W, Ho, Wo = k["geom"]
         M = N * Ho * Wo
-        gp = torch.zeros(c.cout, c.Kp, device=dev)
-        self._gemm_tn(dy16, k["cols"], gp, M, c.cout, c.Kp)
-        L.check(lib.kzv_ocr_conv_wgrad_unpack(gp.data_ptr(), self.grad(c.conv_key + ".weight").data_ptr(), c.cout, c.cin, c.k, c.k, c.Kp, st), "wgrad_unpack")
+        if len(self.convs) <= 40:                                # packed gradient buffers zeroed at the start of backward(), unpacked in one launch at its end
+            gp = self._gp[self._conv_tables().index[id(c)]]
+            self._gemm_tn(dy16, k["cols"], gp, M, c.cout, c.Kp)
+        else:
+            gp = torch.zeros(c.cout, c.Kp, device=dev)
+            self._gemm_tn(dy16, k["cols"], gp, M, c.cout, c.Kp)
+            L.check(lib.kzv_ocr_conv_wgrad_unpack(gp.data_ptr(), self.grad(c.conv_key + ".weight").data_ptr(), c.cout, c.cin, c.k, c.k, c.Kp, st), "wgrad_unpack")
         if not need_dx:
             return None
         dcols = torch.empty(M, c.Kp, device=dev)
