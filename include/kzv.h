@@ -250,6 +250,12 @@ int kzv_set_rows_max_m(int n);
  * ping-pong (gemm_nt256p.hip), 1 = free-running, two barriers per K-tile (gemm_nt256f.hip).  Same results bit for bit (same
  * per-accumulator summation order).  Default: KZV_NT_FREE (environment) or the library's choice; n < 0 restores the default. */
 int kzv_set_nt_schedule(int n);
+/* Bit 1 of the schedule (n = 2, 3): the epilogues whose bit is set in `mask` (1 << KZV_EPI_*; default all) run on the four-wave
+ * 256x128 kernel, two workgroups per CU out of phase so that one's drain overlaps the other's K loop (gemm_nt256h.hip; shapes
+ * with K % 384 == 0, others keep the 256x256 kernels).  Same results bit for bit.  `us`: how late the second workgroup of a CU
+ * starts (microseconds, ~; KZV_NTH_STAGGER, default 8). */
+int kzv_set_nt_half_epilogues(int mask);
+int kzv_set_nt_half_stagger(int us);
 /* The same choice for the 256x256 weight-gradient kernel behind kzv_gemm_tn (gemm_tn256.hip; KZV_TN_FREE). */
 int kzv_set_tn_schedule(int n);
 /* The generation step's GEMMs with the decoder's LayerNorms folded in (hidden size 256): RoBERTa is post-LN, so every sub-layer

@@ -401,13 +401,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(const TnGroup g) 
 
 }  // namespace
 
-// K-loop schedule of the persistent 256x256 kernel: 0 eight-phase ping-pong (gemm_nt256p.hip), 1 free-running (gemm_nt256f.hip)
+// K-loop schedule of the persistent 256x256 kernel: 0 eight-phase ping-pong (gemm_nt256p.hip), 1 free-running (gemm_nt256f.hip);
+// bit 1 (2, 3): the epilogues of g_nt_half_mask go to the four-wave 256x128 kernel, two workgroups per CU (gemm_nt256h.hip)
 static int g_nt_schedule = -1;
+static int g_nt_half_mask = -1;
 static int nt_schedule() {
-    if (g_nt_schedule < 0) { const char* e = getenv("KZV_NT_FREE"); g_nt_schedule = e ? (atoi(e) != 0) : 0; }
+    if (g_nt_schedule < 0) {
+        const char* e = getenv("KZV_NT_FREE"); g_nt_schedule = e ? (atoi(e) != 0) : 0;
+        const char* h = getenv("KZV_NT_HALF"); if (h && atoi(h)) g_nt_schedule |= 2;
+    }
     return g_nt_schedule;
 }
-extern "C" int kzv_set_nt_schedule(int n) { g_nt_schedule = n < 0 ? -1 : (n != 0); return KZV_OK; }
+static int nt_half_mask() {
+    if (g_nt_half_mask < 0) { const char* e = getenv("KZV_NT_HALF_EPIS"); g_nt_half_mask = e ? atoi(e) : 0x3f; }
+    return g_nt_half_mask;
+}
+extern "C" int kzv_set_nt_schedule(int n) { g_nt_schedule = n < 0 ? -1 : (n & 3); return KZV_OK; }
+extern "C" int kzv_set_nt_half_epilogues(int mask) { g_nt_half_mask = mask; return KZV_OK; }
 
 // validation of a kzv_gemm_nt call and its kernel parameter block (shared with the dgrad + wgrad pair launch of gemm_tn256.hip)
 int kzv_nt_params(const kzv_gemm_nt_args* a, int epilogue, NtParams* out) {
@@ -446,7 +456,10 @@ extern "C" int kzv_gemm_nt(const kzv_gemm_nt_args* a, int epilogue, void* stream
     static int p_gelu = -1;      // dev knob: the two-store GELU epilogues on the persistent kernel too (A/B; default off)
     if (p_gelu < 0) { const char* e = getenv("KZV_NT256P_GELU"); p_gelu = e ? atoi(e) : 0; }
     const bool two_store = !p_gelu && (epilogue == KZV_EPI_GELU || epilogue == KZV_EPI_GELU_F32);
-    if (nt_schedule() && use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256f_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
+    static int half_maxk = -1;   // the four-wave kernel's K loop is latency-bound (three-group ring): it pays only where the drain is a large part of a tile
+    if (half_maxk < 0) { const char* e = getenv("KZV_NTH_MAX_K"); half_maxk = e ? atoi(e) : 1 << 30; }
+    if ((nt_schedule() & 2) && ((nt_half_mask() >> epilogue) & 1) && p.K <= half_maxk && kzv_cu_reserve() == 0 && kzv_nt256h_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
+    if ((nt_schedule() & 1) && use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256f_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
     if (use_p && !two_store && kzv_cu_reserve() == 0 && kzv_nt256p_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
     if (kzv_nt256_launch(p, epilogue, s)) return kzv_check_launch("gemm_nt");
 #define KZV_NT_CASE(E, WM, WN, NS, KB, AD)                                                                \

@@ -93,6 +93,8 @@ int kzv_nt256_launch(const NtParams& p, int epilogue, hipStream_t s);
 int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s);
 // gemm_nt256f.hip (free-running schedule: two barriers per K-tile, loads hidden under each wave's own MFMAs): same contract.
 int kzv_nt256f_launch(const NtParams& p, int epilogue, hipStream_t s);
+// gemm_nt256h.hip (four waves, 256x128 tile, two workgroups per CU out of phase, free-running K loop; K % 384 == 0): same contract.
+int kzv_nt256h_launch(const NtParams& p, int epilogue, hipStream_t s);
 // fp8 (e4m3) operands on the block-scaled MFMA, same persistent schedule (gemm_nt256p.hip); epilogues BF16, GELU, RESID, DGELU.
 // Returns KZV_OK or an error: there is no other fp8 kernel to fall back to.
 int kzv_nt256p_fp8_launch(const NtParams& p, int epilogue, hipStream_t s);

@@ -117,6 +117,8 @@ SYMBOLS = {
     "kzv_gemm_nt": (C.c_int, [C.POINTER(kzv_gemm_nt_args), C.c_int, _P]),
     "kzv_set_rows_max_m": (C.c_int, [C.c_int]),
     "kzv_set_nt_schedule": (C.c_int, [C.c_int]),
+    "kzv_set_nt_half_epilogues": (C.c_int, [C.c_int]),
+    "kzv_set_nt_half_stagger": (C.c_int, [C.c_int]),
     "kzv_set_tn_schedule": (C.c_int, [C.c_int]),
     "kzv_gemm_rows_ln": (C.c_int, [C.POINTER(kzv_gemm_rows_ln_args), C.c_int, _P]),
     "kzv_gemm_nt_fp8": (C.c_int, [C.POINTER(kzv_gemm_nt_fp8_args), C.c_int, _P]),

@@ -129,6 +129,36 @@ def test_gemm_nt_free_running_schedule_is_bit_identical_to_the_ping_pong(lib, M,
         L.check(lib.kzv_set_nt_schedule(-1), "set_nt_schedule")
 
 
+@pytest.mark.parametrize("M,N,K,nv,epi", [(41216, 768, 768, 768, "bf16"), (24600, 1024, 384, 1000, "resid"), (24600, 1024, 384, 1000, "gelu"),
+                                          (24600, 1024, 768, 1024, "f32"), (33024, 768, 1536, 768, "dgelu")])
+def test_gemm_nt_four_wave_kernel_is_bit_identical_to_the_256x256_kernels(lib, M, N, K, nv, epi):
+    """kzv_set_nt_schedule(2): the 256x128 kernel of four waves, two workgroups per CU (gemm_nt256h.hip; round 4's build of VERDICT
+    r03 item 3: one workgroup's drain under the other's K loop).  Not the default -- its three-group LDS ring leaves the K loop
+    latency-bound, profiles/r04_kloop_ablation.md section 4 -- but it is the same arithmetic in the same order: interior and edge
+    tiles, n_valid < N, both outputs of the GELU epilogue, six repeats."""
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K, device=DEV).bfloat16()
+    B = (torch.randn(nv, K, device=DEV) * 0.1).bfloat16()
+    bias = torch.randn(nv, device=DEV)
+    res = torch.randn(M, N, device=DEV) if epi == "resid" else None
+    aux = (torch.rand(M, N, device=DEV) * 1.2).bfloat16() if epi == "dgelu" else torch.zeros(M, N, dtype=torch.bfloat16, device=DEV) if epi == "gelu" else None
+    code = {"bf16": L.EPI_BF16, "f32": L.EPI_F32, "resid": L.EPI_RESID, "dgelu": L.EPI_DGELU, "gelu": L.EPI_GELU}[epi]
+    kw = dict(bias=None if epi == "dgelu" else bias, n_store=N, resid=res, aux=aux, drop_p=0.1 if epi == "resid" else 0.0, key=11)
+    try:
+        L.check(lib.kzv_set_nt_schedule(0), "set_nt_schedule")
+        ref = _gemm_nt(lib, A, B, code, **kw)
+        ref_aux = aux.clone() if epi == "gelu" else None
+        L.check(lib.kzv_set_nt_schedule(2), "set_nt_schedule")
+        for _ in range(6):
+            if epi == "gelu":
+                aux.zero_()
+            assert torch.equal(_gemm_nt(lib, A, B, code, **kw), ref)
+            if epi == "gelu":
+                assert torch.equal(aux, ref_aux)
+    finally:
+        L.check(lib.kzv_set_nt_schedule(-1), "set_nt_schedule")
+
+
 def test_gemm_nt_padded_columns_are_zero(lib, small_gemm_kernel):
     A = torch.randn(130, 64, device=DEV).bfloat16()
     B = torch.randn(157, 64, device=DEV).bfloat16()
