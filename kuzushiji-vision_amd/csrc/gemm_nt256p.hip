@@ -460,7 +460,8 @@ int kzv_nt256p_launch(const NtParams& p, int epilogue, hipStream_t s) {
     const int tiles = ((p.M + 255) / 256) * tilesN;
     if (p.K < 128 || p.K % 128 || tiles < nt256p_min_tiles()) return 0;   // even number of K-tiles (odd: gemm_nt256.hip)
     if ((uint64_t)256 * (uint64_t)p.lda * 2 > 0xffffffffull || (uint64_t)p.n_valid * (uint64_t)p.ldb * 2 > 0xffffffffull) return 0;   // 32-bit DMA offsets
-    const int grid = tiles < device_cus() ? tiles : device_cus();
+    int grid = tiles < device_cus() ? tiles : device_cus();
+    { const char* e = getenv("KZV_NT_GRID"); const int g = e ? atoi(e) : 0; if (g > 0 && g < grid) grid = g; }   // dev: fewer persistent workgroups (two-chain experiment)
 #define KZV_NT256P_CASE(E)                                                                                          \
     case E: {                                                                                                       \
         static bool attr_done = false;                                                                              \

@@ -642,7 +642,9 @@ int kzv_tn256_launch(const TnParams& p0, hipStream_t s) {
     if ((uint64_t)64 * (uint64_t)p0.ldp * 2 + (uint64_t)p0.N * 2 > 0xffffffffull || (uint64_t)64 * (uint64_t)p0.ldq * 2 + (uint64_t)p0.K * 2 > 0xffffffffull) return 0;
     TnParams p = p0;
     // one workgroup per CU in total; every split keeps >= 8 reduction stages (and at least 2: the prologue stages two)
-    int splits = (device_cus() - kzv_cu_reserve()) / tiles;      // leave the reserved CUs to a concurrent collective
+    int cus = device_cus() - kzv_cu_reserve();
+    { const char* e = getenv("KZV_TN_CUS"); const int g = e ? atoi(e) : 0; if (g > 0 && g < cus) cus = g; }   // dev: two-stream experiment
+    int splits = cus / tiles;      // leave the reserved CUs to a concurrent collective
     if (splits > tok_tiles / 8) splits = tok_tiles / 8;
     if (splits < 1) splits = 1;
     int chunk_tiles = (tok_tiles + splits - 1) / splits;
