@@ -529,6 +529,150 @@ __global__ __launch_bounds__(512) void dec_lin_kernel(const DecLin p) {
     }
 }
 
+// ---- a decoder layer's BACKWARD linear chains (round 4, VERDICT r03 item 5, second half) ---------------------------------------------
+// Between the two attention backwards a RobertaLayer's backward is row-local too (HF modeling_roberta.py:421-464 read upwards):
+//   [input gradient of the Linear below a LayerNorm (+ the residual gradient)] -> LayerNorm backward -> [dropout mask, bf16] ->
+//   [input gradient of the Linear above it]
+// three times per layer (LN3: next layer's qkv | fc2 with gelu';  LN2: fc1 | cross output;  LN1: cross query | self output).  As
+// launches these were gemm_nt / dec_lin (12.5 - 20.7 us) + ln_bwd_fast<1> (15.5 us) + gemm_nt / dec_lin (7.4 - 20.7 us); one workgroup
+// takes 64 rows through all three with the forward chains' machinery (weights in fragment order through chain_gemm's window, operand
+// tiles in LDS, every tensor out as whole rows).  Same arithmetic and rounding points as the launches it replaces: fp32 GEMM result
+// + fp32 residual gradient, ln_bwd_fast_kernel's row arithmetic (lane = 4 columns, wave_sum), bf16(mask * dx) as the next operand,
+// bf16 output (times the saved gelu' for fc2).  The weight gradients (which read dy16 / out2) stay the grouped gemm_tn launch; gamma /
+// beta partial sums go to layernorm.hip's regions (one atomic per column and workgroup).
+struct SegBwd {
+    const bf16_t* a; const bf16_t* wp1; const float* resid;
+    const float* x; const float* st; const float* gamma;
+    float* dsum; bf16_t* dy16; Drop odrop; float* partial;
+    const bf16_t* wp2; const bf16_t* aux; bf16_t* out2; int M;
+};
+template <int KS1, int NP2>
+__global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K1 = KS1 * 32, LDA = K1 + 8, N2 = NP2 * 256, LDO = N2 + 8;
+    bf16_t* a1 = (bf16_t*)smem;                                   // [RM][LDH] bf16(mask * dx): GEMM 2's operand
+    char* xr = smem + LDS_A1;                                     // GEMM 1's operand rows -> the fp32 d tile -> partial sums -> GEMM 2's output rows
+    bf16_t* at = (bf16_t*)xr; float* t32 = (float*)xr; bf16_t* ot = (bf16_t*)xr;
+    const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * RM;
+    bf16x8 R[WIN];
+    fill_window<2, KS1>(R, wave_frags<2, KS1>(p.wp1, w), opaque(lane0));
+    {
+        const int t2 = opaque(tid);
+#pragma unroll
+        for (int q = 0; q < RM * (K1 / 8) / 512; ++q) {
+            const int idx = t2 + q * 512, row = idx / (K1 / 8), ch = idx - row * (K1 / 8);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m0 + row < p.M) v = *(const uint4*)(p.a + (int64_t)(m0 + row) * K1 + ch * 8);
+            *(uint4*)(at + row * LDA + ch * 8) = v;
+        }
+    }
+    wg_barrier();
+    {
+        const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
+        f32x4 acc[2][RT];
+        chain_gemm<2, KS1, 2, 8>(R, wave_frags<2, KS1>(p.wp1, w), wave_frags<2, 8>(p.wp2, w), at, LDA, lane, acc);
+        wg_barrier();                                             // every wave has read the operand rows: the fp32 tile takes their place
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n0 = (w + 8 * c) * 16 + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) *(f32x4*)(t32 + (rt * 16 + l15) * LDS_ + n0) = acc[c][rt];
+        }
+    }
+    wg_barrier();
+    float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0);
+    {   // LayerNorm backward, wave w: rows 8 w .. 8 w + 7 (ln_bwd_fast_kernel<1, true, false>'s arithmetic)
+        const int lane = opaque(lane0);
+        const float4 gm = *(const float4*)(p.gamma + lane * 4);
+        const float invH = 1.f / (float)HD;
+#pragma unroll
+        for (int q = 0; q < RM / 8; ++q) {
+            const int row = w * (RM / 8) + q, m = m0 + row;
+            if (m >= p.M) {                                       // wave-uniform
+                *(uint2*)(a1 + row * LDH + lane * 4) = make_uint2(0, 0);
+                continue;
+            }
+            float4 d = *(const float4*)(t32 + row * LDS_ + lane * 4);
+            if (p.resid) { const float4 r = *(const float4*)(p.resid + (int64_t)m * HD + lane * 4); d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
+            const float4 xv = *(const float4*)(p.x + (int64_t)m * HD + lane * 4);
+            const float mean = p.st[2 * (int64_t)m], rstd = p.st[2 * (int64_t)m + 1];
+            float4 xh, gy;
+            float s1 = 0.f, s2 = 0.f;
+            xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            gy = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+            s1 += gy.x + gy.y + gy.z + gy.w;
+            s2 += gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w;
+            dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
+            db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+            const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+            float4 o = make_float4(rstd * (gy.x - m1 - xh.x * m2), rstd * (gy.y - m1 - xh.y * m2),
+                                   rstd * (gy.z - m1 - xh.z * m2), rstd * (gy.w - m1 - xh.w * m2));
+            *(float4*)(p.dsum + (int64_t)m * HD + lane * 4) = o;
+            if (p.odrop.thr16) {
+                const unsigned e = (unsigned)m * (unsigned)HD + 4u * lane;
+                const unsigned b0 = drop_bits(p.odrop.key, e >> 1), b1 = drop_bits(p.odrop.key, (e >> 1) + 1);
+                o.x *= drop_keep(b0, 0, p.odrop.thr16, p.odrop.inv_keep); o.y *= drop_keep(b0, 1, p.odrop.thr16, p.odrop.inv_keep);
+                o.z *= drop_keep(b1, 0, p.odrop.thr16, p.odrop.inv_keep); o.w *= drop_keep(b1, 1, p.odrop.thr16, p.odrop.inv_keep);
+            }
+            const uint2 h = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+            *(uint2*)(p.dy16 + (int64_t)m * HD + lane * 4) = h;
+            *(uint2*)(a1 + row * LDH + lane * 4) = h;
+        }
+    }
+    wg_barrier();                                                 // the fp32 tile is dead: it holds the eight waves' gamma / beta partial sums
+    {
+        const int lane = opaque(lane0);
+        float4* sg = (float4*)xr + (w * 2) * 64;
+        sg[lane] = dg; sg[64 + lane] = db;
+    }
+    wg_barrier();
+    {
+        const int t2 = opaque(tid), col = t2 & 255, which = t2 >> 8;
+        const float* sf = (const float*)xr;
+        float a = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) a += sf[(ww * 2 + which) * HD + col];
+        atomicAdd(p.partial + (size_t)(blockIdx.x % KZV_LN_SLOTS) * 2 * HD + which * HD + col, a);
+    }
+    wg_barrier();                                                 // ... and now GEMM 2's output rows
+    {
+        const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int pass = 0; pass < NP2; ++pass) {
+            uint2 u[2][RT];
+            if constexpr (NP2 > 1) {                              // fc2: the forward's saved gelu'(pre-activation), requested before the MFMAs
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int m = m0 + rt * 16 + l15;
+                        u[c][rt] = make_uint2(0, 0);
+                        if (m < p.M) u[c][rt] = *(const uint2*)(p.aux + (int64_t)m * N2 + 256 * pass + (w + 8 * c) * 16 + 4 * g);
+                    }
+            }
+            f32x4 acc[2][RT];
+            if (pass + 1 < NP2) chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), wave_frags<2, 8>(p.wp2 + (int64_t)(pass + 1) * 65536, w), a1, LDH, lane, acc);
+            else chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), nullptr, a1, LDH, lane, acc);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int n0 = 256 * pass + (w + 8 * c) * 16 + 4 * g;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x4 v = acc[c][rt];
+                    if constexpr (NP2 > 1) {
+                        const uint2 uu = u[c][rt];
+                        v[0] *= bf2f((bf16_t)(uu.x & 0xffff)); v[1] *= bf2f((bf16_t)(uu.x >> 16)); v[2] *= bf2f((bf16_t)(uu.y & 0xffff)); v[3] *= bf2f((bf16_t)(uu.y >> 16));
+                    }
+                    *(uint2*)(ot + (rt * 16 + l15) * LDO + n0) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+            }
+        }
+    }
+    wg_barrier();
+    rows_out<32 * NP2>(ot, LDO, p.out2, N2, m0, p.M, opaque(tid));
+}
+
 // every decoder weight of the model -> fragment order, one launch
 struct PackDesc { const uint4* src; uint4* dst; int N, K, t0, n_valid; };
 constexpr int PACK_PER_LAUNCH = 96;        // 32-byte descriptors in the kernel argument block (4 KiB limit)
@@ -601,6 +745,32 @@ int kzv_dec_lin(const bf16_t* a, const bf16_t* wp, void* out, const float* resid
     if (N == 768 && K == 256 && epi == DL_DGELU) KZV_DL(6, 8, DL_DGELU);
 #undef KZV_DL
     return kzv_fail(KZV_E_ARG, "dec_lin: no instance for N %d, K %d, epilogue %d", N, K, epi);
+}
+
+int kzv_dec_bwd_seg(const KzvDecBwdSeg& a, hipStream_t s) {
+    if (!a.a || !a.wp1 || !a.x || !a.st || !a.gamma || !a.dgamma || !a.dbeta || !a.dsum || !a.dy16 || !a.wp2 || !a.out2 || a.M < 1 || (a.K1 != 256 && a.K1 != 768))
+        return kzv_fail(KZV_E_ARG, "dec_bwd_seg: bad argument");
+    bool fold_now = false;
+    float* partial = kzv_ln_partial_region(a.dgamma, a.dbeta, HD, s, &fold_now);
+    if (!partial) return KZV_E_ARG;
+    SegBwd p{a.a, a.wp1, a.resid, a.x, a.st, a.gamma, a.dsum, a.dy16, Drop{0, 1.f, a.drop_key}, partial, a.wp2, a.aux, a.out2, a.M};
+    kzv_drop_params(a.drop_p, &p.odrop.thr16, &p.odrop.inv_keep);
+    const dim3 grid((a.M + RM - 1) / RM);
+#define KZV_SEG(KS1_, NP2_)                                                                                          \
+    do {                                                                                                             \
+        constexpr int xa = RM * (KS1_ * 32 + 8) * 2, xo = RM * (NP2_ * 256 + 8) * 2, xt = RM * LDS_ * 4;             \
+        constexpr int lds = LDS_A1 + (xa > xo ? (xa > xt ? xa : xt) : (xo > xt ? xo : xt));                          \
+        static bool attr_done = false;                                                                               \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)dec_bwd_seg_kernel<KS1_, NP2_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
+        hipLaunchKernelGGL((dec_bwd_seg_kernel<KS1_, NP2_>), grid, dim3(512), lds, s, p);                            \
+    } while (0)
+    if (a.K1 == 256 && !a.aux) KZV_SEG(8, 1);
+    else if (a.K1 == 768 && !a.aux) KZV_SEG(24, 1);
+    else if (a.K1 == 256) KZV_SEG(8, 3);
+    else KZV_SEG(24, 3);
+#undef KZV_SEG
+    { const int rc = kzv_check_launch("dec_bwd_seg"); if (rc != KZV_OK) return rc; }
+    return fold_now ? kzv_ln_partial_fold(partial, a.dgamma, a.dbeta, HD, s) : KZV_OK;
 }
 
 int kzv_head_ce(const KzvHeadCE& a, hipStream_t s) {

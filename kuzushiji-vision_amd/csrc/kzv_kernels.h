@@ -21,6 +21,11 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
 // folds at once (the per-op C ABI).
 struct KzvLnDeferScope { explicit KzvLnDeferScope(hipStream_t stream); ~KzvLnDeferScope(); hipStream_t s; };
 
+// for kernels that fuse a LayerNorm backward (decoder_chain.hip): see layernorm.hip
+constexpr int KZV_LN_SLOTS = 32;
+float* kzv_ln_partial_region(float* dgamma, float* dbeta, int H, hipStream_t s, bool* fold_now);
+int kzv_ln_partial_fold(float* partial, float* dgamma, float* dbeta, int H, hipStream_t s);
+
 // elementwise.hip
 int kzv_im2row(const float* px, bf16_t* out, int B, int C, int H, int W, int ph, int pw, hipStream_t s);
 // gw / gw_max: patches per grid row of this batch / of the position table (width buckets: row of patch p = (p / gw) * gw_max + p % gw)
@@ -125,4 +130,16 @@ int kzv_head_ce(const KzvHeadCE& a, hipStream_t s);
 #define KZV_PACK_MAX_JOBS (12 * KZV_DECODE_FUSED_MAX_LAYERS + 4)
 // one input-gradient GEMM of the decoder on the row-panel scheme (decoder_chain.hip): out[M, N] = a[M, K] . (packed W^T)  [+ resid | * aux]
 int kzv_dec_lin(const bf16_t* a, const bf16_t* wp, void* out, const float* resid, const bf16_t* aux, int M, int N, int K, int epi, hipStream_t s);
-int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s);       // [N, K] row-major copies -> fragment order, one launch
+int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s);
+// One row-local segment of a decoder layer's BACKWARD in one launch (decoder_chain.hip, dec_bwd_seg_kernel):
+//   d = a[M, K1] . (packed W1^T) (+ resid)          the input gradient of the Linear BELOW a LayerNorm (+ the residual gradient)
+//   ds = LayerNorm backward of d (x = the LayerNorm's forward input, st = (mean, rstd), gamma)  -> dsum fp32, dy16 = bf16(dropout mask * ds)
+//   out2 = dy16 . (packed W2^T)  [* aux]            the input gradient of the Linear ABOVE it: bf16 [M, 256] or, with aux, [M, 768] (DGELU)
+// K1 = 256 or 768; dgamma / dbeta receive the LayerNorm's weight gradients (through the partial-sum regions of layernorm.hip).
+struct KzvDecBwdSeg {
+    const bf16_t* a; int K1; const bf16_t* wp1; const float* resid;
+    const float* x; const float* st; const float* gamma; float* dgamma; float* dbeta;
+    float* dsum; bf16_t* dy16; float drop_p; uint32_t drop_key;
+    const bf16_t* wp2; const bf16_t* aux; bf16_t* out2; int M;
+};
+int kzv_dec_bwd_seg(const KzvDecBwdSeg& a, hipStream_t s);       // [N, K] row-major copies -> fragment order, one launch

@@ -470,6 +470,29 @@ int kzv_ln_bwd_ex(const void* dy, int dy_is_f32, const float* x, const float* st
     return kzv_check_launch("layernorm_bwd");
 }
 
+// A kernel that fuses a LayerNorm backward (decoder_chain.hip's backward segments) accumulates its gamma / beta partial sums the way
+// ln_bwd_fast_kernel does (one float atomic per column and workgroup into slot blockIdx % LN_SLOTS of a zeroed [LN_SLOTS][2][H]
+// region): this hands out the region, with kzv_ln_bwd_ex's bookkeeping.  Inside a KzvLnDeferScope the fold joins the scope's single
+// launch (*fold_now = false); otherwise the caller launches its kernel and then calls kzv_ln_partial_fold.
+static_assert(LN_SLOTS == KZV_LN_SLOTS, "kzv_kernels.h: KZV_LN_SLOTS");
+float* kzv_ln_partial_region(float* dgamma, float* dbeta, int H, hipStream_t s, bool* fold_now) {
+    float* partial = ln_partials();
+    if (!partial || !dgamma || !dbeta || H % 4 || H > MAXC * 256) { (void)kzv_fail(KZV_E_ARG, "layernorm partial region: bad argument or no buffer"); return nullptr; }
+    *fold_now = g_ln_defer <= 0;
+    if (g_ln_defer > 0) {
+        bool same_out = false;
+        for (const LnFold& e : g_ln_pending) same_out |= e.dgamma == dgamma || e.dbeta == dbeta;
+        if (((int)g_ln_pending.size() == LN_REGIONS - 1 || same_out) && ln_flush(s) != KZV_OK) return nullptr;
+        partial += (1 + g_ln_pending.size()) * LN_REGION_FLOATS;
+        g_ln_pending.push_back(LnFold{partial, dgamma, dbeta, H});
+    }
+    return partial;
+}
+int kzv_ln_partial_fold(float* partial, float* dgamma, float* dbeta, int H, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, s, partial, dgamma, dbeta, H);
+    return kzv_check_launch("layernorm_bwd_fold");
+}
+
 KzvLnDeferScope::KzvLnDeferScope(hipStream_t stream) : s(stream) { ++g_ln_defer; }
 KzvLnDeferScope::~KzvLnDeferScope() { if (--g_ln_defer == 0) (void)ln_flush(s); }
 

@@ -329,10 +329,11 @@ enum { SITE_ENC_EMB = KZV_SITE_ENC_EMB, SITE_ENC_L = KZV_SITE_ENC_LAYER(0, 0), S
 inline uint32_t key(const kzv_model* m, uint32_t site) { return kzv_drop_key(m->seed, site); }
 inline float dp(const kzv_model* m, float p) { return m->train ? p : 0.f; }
 
-// decoder_chain.hip: the linear chains of a decoder layer as two launches (KZV_DEC_CHAIN, kzv_set_dec_chain; default on)
+// decoder_chain.hip: the linear chains of a decoder layer as two launches (KZV_DEC_CHAIN, kzv_set_dec_chain): 0 = off, 1 = the forward
+// chains (+ the 256 x 256 input gradients on the row-panel kernel), 2 (default) = also the backward's row-local segments, one launch each
 int g_dec_chain = -1;
 int dec_chain_mode() {
-    if (g_dec_chain < 0) { const char* e = getenv("KZV_DEC_CHAIN"); g_dec_chain = e ? (atoi(e) != 0) : 1; }
+    if (g_dec_chain < 0) { const char* e = getenv("KZV_DEC_CHAIN"); g_dec_chain = e ? atoi(e) : 2; if (g_dec_chain < 0 || g_dec_chain > 2) g_dec_chain = 2; }
     return g_dec_chain;
 }
 bool dec_pack_wanted(const kzv_model* m);
@@ -628,7 +629,11 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
     const bf16_t* x_last_h = m->Ld ? m->da[m->Ld - 1].x3h : m->xd0h;
     KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, x_last_h, Hd, G + m->hd_w, Md, Hd, Hd, Hd, nullptr));
-    if (rows_dgrad) KZV_TRY(kzv_dec_lin(m->dy_d, tp(m->Ld, 0), m->dx_d, nullptr, nullptr, Md, Hd, Hd, 1, s));
+    // the three row-local segments of a layer's backward, one launch each (decoder_chain.hip dec_bwd_seg_kernel): the head dense's input
+    // gradient becomes the first GEMM of the top layer's first segment
+    const bool segs = rows_dgrad && dec_chain_mode() >= 2 && m->Ld > 0;
+    if (segs) {}
+    else if (rows_dgrad) KZV_TRY(kzv_dec_lin(m->dy_d, tp(m->Ld, 0), m->dx_d, nullptr, nullptr, Md, Hd, Hd, 1, s));
     else KZV_TRY(gemm(m->dy_d, Hd, m->w_hd, true, Md, Hd, Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_F32, s));
     KZV_TRY(wgrad_flush(m, s));          // LM head (tied word embedding) + head dense: before dy_d is rewritten
     // ---- decoder layers, last to first -----------------------------------------------------------------
@@ -637,6 +642,35 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
         const DecLayerP& d = m->dp[i];
         const uint32_t site = SITE_DEC_L + 8 * i;
         const bf16_t* xh = i ? m->da[i - 1].x3h : m->xd0h;
+        if (segs) {
+            const float hp = dp(m, c.dec_hidden_dropout);
+            const bool top = i == m->Ld - 1;
+            // [head dense | the layer above's qkv] -> LN3 -> fc2 (gelu')
+            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{top ? m->dy_d : m->dqkv_d, top ? Hd : 3 * Hd, tp(top ? m->Ld : i + 1, 0), top ? nullptr : m->dsum_d,
+                                                 a.s3, a.st3, P + d.ln3w, G + d.ln3w, G + d.ln3b, m->dsum_d, m->dy_d, hp, key(m, site + 4),
+                                                 tp(i, 6 * HHd + FHd), a.pre, m->dbig_d, Md}, s));
+            KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
+            KZV_TRY(wgrad_batch(m, CLS_DBIG, s, m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
+            // fc1 -> LN2 -> cross-attention output projection
+            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{m->dbig_d, Fd, tp(i, 6 * HHd), m->dsum_d, a.s2, a.st2, P + d.ln2w, G + d.ln2w, G + d.ln2b, m->dsum_d, m->dy_d2,
+                                                 hp, key(m, site + 3), tp(i, 5 * HHd), nullptr, m->dctx_d, Md}, s));
+            KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d2, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
+            KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
+                         m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->npa,
+                         dp(m, c.dec_attn_dropout), key(m, site + 2), s));
+            KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
+            // cross-attention query -> LN1 -> self-attention output projection
+            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{m->dq_d, Hd, tp(i, 4 * HHd), m->dsum_d, a.s1, a.st1, P + d.ln1w, G + d.ln1w, G + d.ln1b, m->dsum_d, m->dy_d3,
+                                                 hp, key(m, site + 1), tp(i, 3 * HHd), nullptr, m->dctx_d, Md}, s));
+            KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d3, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
+            KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
+                         m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
+            KZV_TRY(wgrad_batch(m, CLS_DQKV, s, m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
+            if (i == 0)      // the bottom layer's qkv feeds the embedding LayerNorm: its own launch (a lower layer's first segment takes it otherwise)
+                KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+            KZV_TRY(wgrad_flush(m, s));
+            continue;
+        }
         // FFN block: x3 = LN(s3), s3 = x2 + drop(fc2(gelu(fc1(x2))))
         KZV_TRY(wait_cls(m, CLS_DY, s));
         KZV_TRY(kzv_ln_bwd_ex(m->dx_d, 1, a.s3, a.st3, P + d.ln3w, m->dsum_d, 0, G + d.ln3w, G + d.ln3b, Md, Hd, 1, 0, 0.f, 0, s,
@@ -1089,7 +1123,7 @@ static int decode_one_launch_mode() {
     return g_decode_one_launch;
 }
 extern "C" int kzv_set_dec_chain(int on) {
-    if (on < -1 || on > 1) return kzv_fail(KZV_E_ARG, "set_dec_chain: -1 (environment default), 0 or 1");
+    if (on < -1 || on > 2) return kzv_fail(KZV_E_ARG, "set_dec_chain: -1 (environment default), 0, 1 or 2");
     g_dec_chain = on;
     return KZV_OK;
 }

@@ -31,7 +31,7 @@ def _run(cfg, tmp_path, B, Lh, train, seed):
     px, lab = synthetic_batch(cfg, B, Lh, seed=seed, min_chars=1, max_chars=Lh - 2)
     pxt, ids = torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()
     out = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         L.check(lib.kzv_set_dec_chain(mode), "mode")
         m.train() if train else m.eval()
         m.zero_grad()
@@ -48,14 +48,17 @@ def _run(cfg, tmp_path, B, Lh, train, seed):
 @pytest.mark.parametrize("B,Lh,train", [(5, 30, True), (3, 12, True), (7, 23, False)])
 def test_chains_equal_the_launch_per_operation_forward(tmp_path, B, Lh, train):
     cfg = dataclasses.replace(tiny_config(), dec_hidden=256, dec_heads=4, dec_ffn=768, dec_layers=3)       # dropout 0.1 stays on
-    (l0, z0, g0), (l1, z1, g1) = _run(cfg, tmp_path, B, Lh, train, seed=4 + B)
+    (l0, z0, g0), (l1, z1, g1), (l2, z2, g2) = _run(cfg, tmp_path, B, Lh, train, seed=4 + B)
     dz = float((z0 - z1).abs().max())
     print(f"B={B} L={Lh} train={train}: loss {l0:.6f} / {l1:.6f}, largest logit difference {dz:.2e}", end="")
     assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and dz < 1e-4
+    assert abs(l2 - l1) < 2e-6 * max(1.0, abs(l1)) and torch.equal(z1, z2)      # mode 2 changes the backward only (the loss is a sum of float atomics)
     if train:
         dg = float((g0 - g1).abs().max()); sc = float(g0.abs().max())
-        print(f", largest gradient difference {dg:.2e} of {sc:.2e}")
+        dg2 = float((g1 - g2).abs().max())
+        print(f", largest gradient difference {dg:.2e} (forward chains) / {dg2:.2e} (backward segments vs launches) of {sc:.2e}")
         assert dg < 1e-4 * sc                                   # same arithmetic, same dropout bits: differences are summation order at most
+        assert dg2 < 1e-5 * sc                                  # the segments: the launches' arithmetic row by row; gamma / beta partial sums in another order
 
 
 @pytest.mark.parametrize("B,Lh,train,vocab", [(5, 30, True, 4300), (3, 12, True, 100), (7, 23, False, 777), (70, 9, True, 4300)])
@@ -94,7 +97,9 @@ def test_one_launch_lm_head_and_cross_entropy_equals_gemm_plus_ce_kernel(tmp_pat
 def test_chains_at_the_benchmark_decoder_geometry(tmp_path):
     """12 layers, 15 sequences of up to 127 tokens (rows not a multiple of the 64-row workgroup tile), dropout on."""
     cfg = small_config()
-    (l0, z0, g0), (l1, z1, g1) = _run(cfg, tmp_path, 15, cfg.max_pos - cfg.pad_id - 1, True, seed=2)
+    (l0, z0, g0), (l1, z1, g1), (l2, z2, g2) = _run(cfg, tmp_path, 15, cfg.max_pos - cfg.pad_id - 1, True, seed=2)
     dz = float((z0 - z1).abs().max()); dg = float((g0 - g1).abs().max()); sc = float(g0.abs().max())
-    print(f"loss {l0:.6f} / {l1:.6f}, largest logit difference {dz:.2e}, largest gradient difference {dg:.2e} of {sc:.2e}")
+    dg2 = float((g1 - g2).abs().max())
+    print(f"loss {l0:.6f} / {l1:.6f}, largest logit difference {dz:.2e}, largest gradient difference {dg:.2e} / {dg2:.2e} (backward segments) of {sc:.2e}")
     assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and dz < 1e-4 and dg < 1e-4 * sc
+    assert abs(l2 - l1) < 2e-6 * max(1.0, abs(l1)) and torch.equal(z1, z2) and dg2 < 1e-5 * sc
