@@ -73,8 +73,14 @@ __device__ __forceinline__ void chain_gemm(bf16x8 (&R)[WIN], const char* wb, con
 #ifdef KZV_STAMPS      // diagnostic build (tools/dev/stamps_chain.py): the phase timeline of workgroup 0 of the last dec_chain_b launch
 __device__ long long g_chain_stamps[32];
 #define CH_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_chain_stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#ifndef KZV_STAMP_SEG_KS1
+#define KZV_STAMP_SEG_KS1 8
+#define KZV_STAMP_SEG_NP2 1
+#endif
+#define SEG_STAMP(k) do { if (KS1 == KZV_STAMP_SEG_KS1 && NP2 == KZV_STAMP_SEG_NP2) CH_STAMP(k); } while (0)
 #else
 #define CH_STAMP(k)
+#define SEG_STAMP(k)
 #endif
 
 struct Drop { unsigned thr16; float inv_keep; unsigned key; };
@@ -99,9 +105,29 @@ __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, bf16_t
 // global memory from the MFMA layout -- a lane holds 4 columns of 16 different rows there, i.e. 32- / 64-byte pieces of 16 rows per
 // store instruction, which is what made the first version of these kernels 2.7x slower than its byte count: every tensor leaves
 // through an LDS tile as whole rows.)
-__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const Resid& resid, const Drop& d,
+// The epilogue's global operands (residual rows in the MFMA layout: 64-byte pieces of 16 rows per instruction, plus the row statistics when
+// the residual is recomputed) are requested BEFORE the GEMM whose result they meet -- behind it they were 6 - 8 k cycles of exposed latency
+// per epilogue (tools/dev/stamps_chain.py).  Rows past M read the last row (never used).
+struct ResidRegs { float4 v[2][RT]; float mean[RT], rstd[RT]; };
+__device__ __forceinline__ void resid_prefetch(const Resid& resid, ResidRegs& r, int m0, int M, int w, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const float* src = resid.x ? resid.x : resid.s;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t m = min(m0 + rt * 16 + l15, M - 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) r.v[c][rt] = *(const float4*)(src + m * HD + (w + 8 * c) * 16 + 4 * g);
+        r.mean[rt] = 0.f; r.rstd[rt] = 0.f;
+        if (!resid.x) { r.mean[rt] = resid.st[2 * m]; r.rstd[rt] = resid.st[2 * m + 1]; }
+    }
+}
+__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const Resid& resid, const ResidRegs& pre, const Drop& d,
                                                float* s_lds, int m0, int M, int w, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
+    // The prefetched operands were requested one GEMM ago; retire them by hand.  hipcc's own count for registers loaded that early was
+    // too lenient once this epilogue's per-row guards split the control flow: logits differed from run to run (tools/dev/r5_det.py)
+    // until this wait was added -- by now the loads have had a whole GEMM to land, so it costs next to nothing.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n0 = (w + 8 * c) * 16 + 4 * g;
@@ -118,10 +144,10 @@ __device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const 
                     v[2] *= drop_keep(b1, 0, d.thr16, d.inv_keep); v[3] *= drop_keep(b1, 1, d.thr16, d.inv_keep);
                 }
                 float4 x4;
-                if (resid.x) x4 = *(const float4*)(resid.x + (int64_t)m * HD + n0);
+                if (resid.x) x4 = pre.v[c][rt];
                 else {
-                    const float4 sv = *(const float4*)(resid.s + (int64_t)m * HD + n0), gm = *(const float4*)(resid.g + n0), bt = *(const float4*)(resid.b + n0);
-                    const float mean = resid.st[2 * (int64_t)m], rstd = resid.st[2 * (int64_t)m + 1];
+                    const float4 sv = pre.v[c][rt], gm = *(const float4*)(resid.g + n0), bt = *(const float4*)(resid.b + n0);
+                    const float mean = pre.mean[rt], rstd = pre.rstd[rt];
                     const float a0 = sv.x - mean, a1 = sv.y - mean, a2 = sv.z - mean, a3 = sv.w - mean;
                     x4 = make_float4(a0 * rstd * gm.x + bt.x, a1 * rstd * gm.y + bt.y, a2 * rstd * gm.z + bt.z, a3 * rstd * gm.w + bt.w);
                 }
@@ -134,19 +160,53 @@ __device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const 
 // x (fp32) and xh (bf16) to global, xh also to the LDS operand tile, (mean, rstd) to stats
 __device__ __forceinline__ void ln_rows(const float* s_lds, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ s_out,
                                         float* __restrict__ x_out, bf16_t* __restrict__ xh_out, float* __restrict__ stats, bf16_t* a_lds, int m0, int M, int w, int lane) {
+    constexpr int NR = RM / 8;
     const float4 gm = *(const float4*)(gamma + lane * 4), bt = *(const float4*)(beta + lane * 4);
+    float4 v8[NR];              // every row out of LDS before the first LDS store below: hipcc cannot tell the sum tile from the operand tile and
+#pragma unroll                  // would otherwise keep each row's LDS read behind the previous row's write
+    for (int q = 0; q < NR; ++q) v8[q] = *(const float4*)(s_lds + (w * NR + q) * LDS_ + lane * 4);
+    // The two wave reductions of a row are 12 dependent ds_bpermute round trips (~120 cycles each): row by row that was 1.8 k cycles per
+    // row, 14 k per LayerNorm phase (tools/dev/stamps_chain.py).  The eight rows of a wave are independent, so each butterfly step is
+    // taken for all of them together -- the same additions in the same order per row (wave_sum's), eight shuffles in flight at a time.
+    float t8[NR], mean8[NR], rstd8[NR];
 #pragma unroll
-    for (int q = 0; q < RM / 8; ++q) {
-        const int row = w * (RM / 8) + q, m = m0 + row;
+    for (int q = 0; q < NR; ++q) t8[q] = v8[q].x + v8[q].y + v8[q].z + v8[q].w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float u8[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) u8[q] = __shfl_xor(t8[q], o, 64);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) t8[q] += u8[q];
+    }
+    float4 c8[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        mean8[q] = t8[q] / (float)HD;
+        c8[q] = make_float4(v8[q].x - mean8[q], v8[q].y - mean8[q], v8[q].z - mean8[q], v8[q].w - mean8[q]);
+        t8[q] = c8[q].x * c8[q].x + c8[q].y * c8[q].y + c8[q].z * c8[q].z + c8[q].w * c8[q].w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float u8[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) u8[q] = __shfl_xor(t8[q], o, 64);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) t8[q] += u8[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) rstd8[q] = rsqrtf(t8[q] / (float)HD + eps);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int row = w * NR + q, m = m0 + row;
         if (m >= M) {                                 // wave-uniform
             *(uint2*)(a_lds + row * LDH + lane * 4) = make_uint2(0, 0);
             continue;
         }
-        const float4 v = *(const float4*)(s_lds + row * LDS_ + lane * 4);
+        const float4 v = v8[q];
         *(float4*)(s_out + (int64_t)m * HD + lane * 4) = v;
-        const float mean = wave_sum(v.x + v.y + v.z + v.w) / (float)HD;
-        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) / (float)HD + eps);
+        const float mean = mean8[q], rstd = rstd8[q];
+        const float a = c8[q].x, b = c8[q].y, c = c8[q].z, d = c8[q].w;
         if (lane == 0) { stats[2 * (int64_t)m] = mean; stats[2 * (int64_t)m + 1] = rstd; }
         const float o0 = a * rstd * gm.x + bt.x, o1 = b * rstd * gm.y + bt.y, o2 = c * rstd * gm.z + bt.z, o3 = d * rstd * gm.w + bt.w;
         const uint2 h = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
@@ -199,12 +259,14 @@ __global__ __launch_bounds__(512) void dec_chain_a_kernel(const SegA p) {
     bf16x8 R[WIN];
     fill_window<2, 8>(R, wave_frags<2, 8>(p.wo, w), opaque(lane0));
     load_rows(p.ctx, a1, m0, p.M, opaque(tid));
+    ResidRegs rr;
+    resid_prefetch(p.xres, rr, m0, p.M, w, opaque(lane0));
     wg_barrier();
     {
         const int lane = opaque(lane0);
         f32x4 acc[2][RT];
         chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wo, w), wave_frags<2, 8>(p.wcq, w), a1, LDH, lane, acc);
-        resid_epilogue(acc, p.bo, p.xres, p.drop, ssum, m0, p.M, w, lane);
+        resid_epilogue(acc, p.bo, p.xres, rr, p.drop, ssum, m0, p.M, w, lane);
     }
     wg_barrier();                // every wave has read the ctx tile and written its part of the sum tile
     ln_rows(ssum, p.g1, p.b1, p.eps, p.s1, p.x1, p.x1h, p.st1, a1, m0, p.M, w, opaque(lane0));
@@ -231,13 +293,15 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     CH_STAMP(0);
     fill_window<2, 8>(R, wave_frags<2, 8>(p.wco, w), opaque(lane0));
     load_rows(p.cctx, a1, m0, p.M, opaque(tid));
+    ResidRegs rr;
+    resid_prefetch(p.x1, rr, m0, p.M, w, opaque(lane0));
     wg_barrier();
     CH_STAMP(1);
     {   // s2 = drop(cctx Wco^T + b) + x1
         const int lane = opaque(lane0);
         f32x4 acc[2][RT];
         chain_gemm<2, 8, 6, 8>(R, wave_frags<2, 8>(p.wco, w), wave_frags<6, 8>(p.wfc1, w), a1, LDH, lane, acc);
-        resid_epilogue(acc, p.bco, p.x1, p.drop3, ssum, m0, p.M, w, lane);
+        resid_epilogue(acc, p.bco, p.x1, rr, p.drop3, ssum, m0, p.M, w, lane);
     }
     wg_barrier();
     CH_STAMP(2);
@@ -277,6 +341,8 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     rows_out<96>(a2, LDW, p.act, FD, m0, p.M, opaque(tid));       // (the last barrier above also covers the activation tile)
     CH_STAMP(6);
     f32x4 acc3[2][RT];
+    const Resid res2{p.x2, p.s2, p.st2, p.g2, p.b2};              // x2: this workgroup's own rows, written above (ln_rows; many barriers ago)
+    resid_prefetch(res2, rr, m0, p.M, w, opaque(lane0));
     {   // s3 = drop(act Wfc2^T + b) + x2
         const int lane = opaque(lane0);
         if (p.wqkv) chain_gemm<2, 24, 6, 8>(R, wave_frags<2, 24>(p.wfc2, w), wave_frags<6, 8>(p.wqkv, w), a2, LDW, lane, acc3);
@@ -284,7 +350,7 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     }
     wg_barrier();                // every wave has read the activation tile: the sum tile (same memory) may be written
     CH_STAMP(7);
-    resid_epilogue(acc3, p.bfc2, Resid{p.x2, p.s2, p.st2, p.g2, p.b2}, p.drop4, ssum, m0, p.M, w, opaque(lane0));      // x2: this workgroup's own rows, written above
+    resid_epilogue(acc3, p.bfc2, res2, rr, p.drop4, ssum, m0, p.M, w, opaque(lane0));
     wg_barrier();
     CH_STAMP(8);
     ln_rows(ssum, p.g3, p.b3, p.eps, p.s3, p.x3, p.x3h, p.st3, a1, m0, p.M, w, opaque(lane0));
@@ -556,6 +622,7 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
     const int tid = threadIdx.x, lane0 = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * RM;
     bf16x8 R[WIN];
+    SEG_STAMP(16);
     fill_window<2, KS1>(R, wave_frags<2, KS1>(p.wp1, w), opaque(lane0));
     {
         const int t2 = opaque(tid);
@@ -567,12 +634,26 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
             *(uint4*)(at + row * LDA + ch * 8) = v;
         }
     }
+    // the LayerNorm backward's global operands of this wave's eight rows, requested now: they arrive under GEMM 1 (rows past M: the last row)
+    float4 xv8[RM / 8], rv8[RM / 8]; float2 st8[RM / 8];
+    {
+        const int lane = opaque(lane0);
+#pragma unroll
+        for (int q = 0; q < RM / 8; ++q) {
+            const int64_t mc = min(m0 + w * (RM / 8) + q, p.M - 1);
+            xv8[q] = *(const float4*)(p.x + mc * HD + lane * 4);
+            rv8[q] = p.resid ? *(const float4*)(p.resid + mc * HD + lane * 4) : make_float4(0, 0, 0, 0);
+            st8[q] = *(const float2*)(p.st + 2 * mc);
+        }
+    }
     wg_barrier();
+    SEG_STAMP(17);
     {
         const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
         f32x4 acc[2][RT];
         chain_gemm<2, KS1, 2, 8>(R, wave_frags<2, KS1>(p.wp1, w), wave_frags<2, 8>(p.wp2, w), at, LDA, lane, acc);
         wg_barrier();                                             // every wave has read the operand rows: the fp32 tile takes their place
+        SEG_STAMP(18);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int n0 = (w + 8 * c) * 16 + 4 * g;
@@ -581,22 +662,26 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
         }
     }
     wg_barrier();
+    SEG_STAMP(19);
     float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0);
     {   // LayerNorm backward, wave w: rows 8 w .. 8 w + 7 (ln_bwd_fast_kernel<1, true, false>'s arithmetic)
         const int lane = opaque(lane0);
         const float4 gm = *(const float4*)(p.gamma + lane * 4);
         const float invH = 1.f / (float)HD;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the operands requested before GEMM 1 (see resid_epilogue: retired by hand)
+        float4 d8[RM / 8];                                        // every row out of LDS before the first LDS store below (hipcc keeps their order otherwise: one row at a time)
+#pragma unroll
+        for (int q = 0; q < RM / 8; ++q) d8[q] = *(const float4*)(t32 + (w * (RM / 8) + q) * LDS_ + lane * 4);
+        // per row ln_bwd_fast_kernel's statements; the two wave sums of the eight rows go through the butterfly together (see ln_rows)
+        float4 xh8[RM / 8], gy8[RM / 8];
+        float s18[RM / 8], s28[RM / 8];
 #pragma unroll
         for (int q = 0; q < RM / 8; ++q) {
-            const int row = w * (RM / 8) + q, m = m0 + row;
-            if (m >= p.M) {                                       // wave-uniform
-                *(uint2*)(a1 + row * LDH + lane * 4) = make_uint2(0, 0);
-                continue;
-            }
-            float4 d = *(const float4*)(t32 + row * LDS_ + lane * 4);
-            if (p.resid) { const float4 r = *(const float4*)(p.resid + (int64_t)m * HD + lane * 4); d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
-            const float4 xv = *(const float4*)(p.x + (int64_t)m * HD + lane * 4);
-            const float mean = p.st[2 * (int64_t)m], rstd = p.st[2 * (int64_t)m + 1];
+            float4 d = d8[q];
+            if (p.resid) { const float4 r = rv8[q]; d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
+            if (m0 + w * (RM / 8) + q >= p.M) d = make_float4(0, 0, 0, 0);      // wave-uniform: rows past M add nothing to gamma / beta
+            const float4 xv = xv8[q];
+            const float mean = st8[q].x, rstd = st8[q].y;
             float4 xh, gy;
             float s1 = 0.f, s2 = 0.f;
             xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
@@ -605,7 +690,26 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
             s2 += gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w;
             dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
             db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
-            const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+            xh8[q] = xh; gy8[q] = gy; s18[q] = s1; s28[q] = s2;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float u1[RM / 8], u2[RM / 8];
+#pragma unroll
+            for (int q = 0; q < RM / 8; ++q) { u1[q] = __shfl_xor(s18[q], o, 64); u2[q] = __shfl_xor(s28[q], o, 64); }
+#pragma unroll
+            for (int q = 0; q < RM / 8; ++q) { s18[q] += u1[q]; s28[q] += u2[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < RM / 8; ++q) {
+            const int row = w * (RM / 8) + q, m = m0 + row;
+            if (m >= p.M) {                                       // wave-uniform
+                *(uint2*)(a1 + row * LDH + lane * 4) = make_uint2(0, 0);
+                continue;
+            }
+            const float rstd = st8[q].y;
+            const float4 xh = xh8[q], gy = gy8[q];
+            const float m1 = s18[q] * invH, m2 = s28[q] * invH;
             float4 o = make_float4(rstd * (gy.x - m1 - xh.x * m2), rstd * (gy.y - m1 - xh.y * m2),
                                    rstd * (gy.z - m1 - xh.z * m2), rstd * (gy.w - m1 - xh.w * m2));
             *(float4*)(p.dsum + (int64_t)m * HD + lane * 4) = o;
@@ -620,6 +724,7 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
             *(uint2*)(a1 + row * LDH + lane * 4) = h;
         }
     }
+    SEG_STAMP(20);
     wg_barrier();                                                 // the fp32 tile is dead: it holds the eight waves' gamma / beta partial sums
     {
         const int lane = opaque(lane0);
@@ -636,6 +741,7 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
         atomicAdd(p.partial + (size_t)(blockIdx.x % KZV_LN_SLOTS) * 2 * HD + which * HD + col, a);
     }
     wg_barrier();                                                 // ... and now GEMM 2's output rows
+    SEG_STAMP(21);
     {
         const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -646,14 +752,14 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        const int m = m0 + rt * 16 + l15;
-                        u[c][rt] = make_uint2(0, 0);
-                        if (m < p.M) u[c][rt] = *(const uint2*)(p.aux + (int64_t)m * N2 + 256 * pass + (w + 8 * c) * 16 + 4 * g);
+                        const int64_t m = min(m0 + rt * 16 + l15, p.M - 1);     // rows past M: the last row's (their products are never stored)
+                        u[c][rt] = *(const uint2*)(p.aux + m * N2 + 256 * pass + (w + 8 * c) * 16 + 4 * g);
                     }
             }
             f32x4 acc[2][RT];
             if (pass + 1 < NP2) chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), wave_frags<2, 8>(p.wp2 + (int64_t)(pass + 1) * 65536, w), a1, LDH, lane, acc);
             else chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), nullptr, a1, LDH, lane, acc);
+            if constexpr (NP2 > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // gelu' (requested before the MFMAs): retired by hand, as above
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int n0 = 256 * pass + (w + 8 * c) * 16 + 4 * g;
@@ -669,8 +775,10 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
             }
         }
     }
+    SEG_STAMP(22);
     wg_barrier();
     rows_out<32 * NP2>(ot, LDO, p.out2, N2, m0, p.M, opaque(tid));
+    SEG_STAMP(23);
 }
 
 // every decoder weight of the model -> fragment order, one launch
