@@ -175,8 +175,11 @@ int kzv_decode_begin(kzv_model* m, void* stream);
 int kzv_set_decode_one_launch(int on);
 /* Training / evaluation forward: the linear chains of a decoder layer -- [output projection + dropout + residual -> LayerNorm ->
  * cross query] and [output projection -> LayerNorm -> fc1 + GELU -> fc2 -> LayerNorm -> the next layer's QKV] -- as TWO launches
- * per layer (csrc/decoder_chain.hip; hidden 256, 4 heads, FFN 768) instead of nine.  1 (default; KZV_DEC_CHAIN), 0: one launch per
- * operation, -1: the environment's default.  Same tensors, same rounding points, same dropout bits. */
+ * per layer (csrc/decoder_chain.hip; hidden 256, 4 heads, FFN 768) instead of nine.  0: one launch per operation; 1: the forward
+ * chains (+ the decoder's 256 x 256 input-gradient GEMMs on the row-panel kernel); 2 (default; KZV_DEC_CHAIN): also the BACKWARD's three
+ * row-local segments per layer (input-gradient GEMM + residual gradient -> LayerNorm backward -> dropout mask -> input-gradient GEMM) as
+ * one launch each, 13 -> 6 launches per layer; -1: the environment's default.  Same tensors, same rounding points, same dropout bits:
+ * logits bit-identical across the three modes, gradients equal up to float-atomic order. */
 int kzv_set_dec_chain(int on);
 /* Training / validation forward without returned logits: lm_head.decoder (HF modeling_roberta.py:888-893, tied weight) + log-softmax +
  * NLL (src/models/trocr_model.py:256,292) + the bf16 gradient of the logits as ONE launch; the [B*T, vocab] fp32 logits are never written

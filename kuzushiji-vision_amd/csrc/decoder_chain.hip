@@ -108,26 +108,37 @@ __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ src, bf16_t
 // The epilogue's global operands (residual rows in the MFMA layout: 64-byte pieces of 16 rows per instruction, plus the row statistics when
 // the residual is recomputed) are requested BEFORE the GEMM whose result they meet -- behind it they were 6 - 8 k cycles of exposed latency
 // per epilogue (tools/dev/stamps_chain.py).  Rows past M read the last row (never used).
-struct ResidRegs { float4 v[2][RT]; float mean[RT], rstd[RT]; };
+// Registers loaded long before their use are retired BY HAND: `s_waitcnt vmcnt(0)` and then every such register through an empty asm,
+// so that no use can be scheduled above the wait (volatile asms keep their order; plain arithmetic does not stay behind one).  hipcc's
+// own count is not enough here: with loads inside uniform branches (the residual's statistics) between the load and its use, the wait it
+// emitted let the use run first -- chain A read rstd = 0 (the register's initial value) in 2 - 5 % of its workgroups once the launch had
+// more workgroups than CUs (slower loads), i.e. residual = beta for 16 rows (tools/dev/r5_det3.py; rounds 3 - 4 before this).
+__device__ __forceinline__ void pin(float& f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ void pin(unsigned& f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ void pin(float4& v) { pin(v.x); pin(v.y); pin(v.z); pin(v.w); }
+__device__ __forceinline__ void pin(float2& v) { pin(v.x); pin(v.y); }
+__device__ __forceinline__ void pin(uint2& v) { pin(v.x); pin(v.y); }
+__device__ __forceinline__ void retire_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+struct ResidRegs { float4 v[2][RT]; float2 st[RT]; };
 __device__ __forceinline__ void resid_prefetch(const Resid& resid, ResidRegs& r, int m0, int M, int w, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
     const float* src = resid.x ? resid.x : resid.s;
+    const float* stp = resid.x ? resid.x : resid.st;         // no branch around a load: a stored residual reads two of its own floats here (unused)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int64_t m = min(m0 + rt * 16 + l15, M - 1);
 #pragma unroll
         for (int c = 0; c < 2; ++c) r.v[c][rt] = *(const float4*)(src + m * HD + (w + 8 * c) * 16 + 4 * g);
-        r.mean[rt] = 0.f; r.rstd[rt] = 0.f;
-        if (!resid.x) { r.mean[rt] = resid.st[2 * m]; r.rstd[rt] = resid.st[2 * m + 1]; }
+        r.st[rt] = *(const float2*)(stp + 2 * m);
     }
 }
-__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const Resid& resid, const ResidRegs& pre, const Drop& d,
+__device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const float* __restrict__ bias, const Resid& resid, const ResidRegs& pre_in, const Drop& d,
                                                float* s_lds, int m0, int M, int w, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
-    // The prefetched operands were requested one GEMM ago; retire them by hand.  hipcc's own count for registers loaded that early was
-    // too lenient once this epilogue's per-row guards split the control flow: logits differed from run to run (tools/dev/r5_det.py)
-    // until this wait was added -- by now the loads have had a whole GEMM to land, so it costs next to nothing.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ResidRegs pre = pre_in;                                   // requested one GEMM ago: retired by hand (see pin)
+    retire_loads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { pin(pre.v[0][rt]); pin(pre.v[1][rt]); pin(pre.st[rt]); }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n0 = (w + 8 * c) * 16 + 4 * g;
@@ -147,7 +158,7 @@ __device__ __forceinline__ void resid_epilogue(const f32x4 (&acc)[2][RT], const 
                 if (resid.x) x4 = pre.v[c][rt];
                 else {
                     const float4 sv = pre.v[c][rt], gm = *(const float4*)(resid.g + n0), bt = *(const float4*)(resid.b + n0);
-                    const float mean = pre.mean[rt], rstd = pre.rstd[rt];
+                    const float mean = pre.st[rt].x, rstd = pre.st[rt].y;
                     const float a0 = sv.x - mean, a1 = sv.y - mean, a2 = sv.z - mean, a3 = sv.w - mean;
                     x4 = make_float4(a0 * rstd * gm.x + bt.x, a1 * rstd * gm.y + bt.y, a2 * rstd * gm.z + bt.z, a3 * rstd * gm.w + bt.w);
                 }
@@ -306,6 +317,9 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     wg_barrier();
     CH_STAMP(2);
     ln_rows(ssum, p.g2, p.b2, p.eps, p.s2, p.x2, p.x2h, p.st2, a1, m0, p.M, w, opaque(lane0));
+    // s2 / st2 come back from global memory below (the fc2 epilogue's residual, read in the MFMA layout by OTHER waves than the ones that
+    // stored them): the stores must have completed before the barrier that orders the two -- a workgroup barrier alone orders LDS only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                // the sum tile is dead from here: the activation tile may be written
     CH_STAMP(3);
     {   // act = gelu(x2 Wfc1^T + b) -> the activation tile; the derivative (saved for the backward, KZV_EPI_GELU) leaves in three
@@ -642,7 +656,7 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
         for (int q = 0; q < RM / 8; ++q) {
             const int64_t mc = min(m0 + w * (RM / 8) + q, p.M - 1);
             xv8[q] = *(const float4*)(p.x + mc * HD + lane * 4);
-            rv8[q] = p.resid ? *(const float4*)(p.resid + mc * HD + lane * 4) : make_float4(0, 0, 0, 0);
+            rv8[q] = *(const float4*)((p.resid ? p.resid : p.x) + mc * HD + lane * 4);      // no branch around a load (unused without a residual)
             st8[q] = *(const float2*)(p.st + 2 * mc);
         }
     }
@@ -664,42 +678,17 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
     wg_barrier();
     SEG_STAMP(19);
     float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0);
-    {   // LayerNorm backward, wave w: rows 8 w .. 8 w + 7 (ln_bwd_fast_kernel<1, true, false>'s arithmetic)
+    {   // LayerNorm backward, wave w: rows 8 w .. 8 w + 7 (ln_bwd_fast_kernel<1, true, false>'s arithmetic: kzv_common.h ln_bwd_*)
         const int lane = opaque(lane0);
         const float4 gm = *(const float4*)(p.gamma + lane * 4);
         const float invH = 1.f / (float)HD;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the operands requested before GEMM 1 (see resid_epilogue: retired by hand)
+        retire_loads();                                           // the operands requested before GEMM 1: retired by hand (see pin)
+#pragma unroll
+        for (int q = 0; q < RM / 8; ++q) { pin(xv8[q]); pin(rv8[q]); pin(st8[q]); }
         float4 d8[RM / 8];                                        // every row out of LDS before the first LDS store below (hipcc keeps their order otherwise: one row at a time)
 #pragma unroll
         for (int q = 0; q < RM / 8; ++q) d8[q] = *(const float4*)(t32 + (w * (RM / 8) + q) * LDS_ + lane * 4);
-        // per row ln_bwd_fast_kernel's statements; the two wave sums of the eight rows go through the butterfly together (see ln_rows)
-        float4 xh8[RM / 8], gy8[RM / 8];
-        float s18[RM / 8], s28[RM / 8];
-#pragma unroll
-        for (int q = 0; q < RM / 8; ++q) {
-            float4 d = d8[q];
-            if (p.resid) { const float4 r = rv8[q]; d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
-            if (m0 + w * (RM / 8) + q >= p.M) d = make_float4(0, 0, 0, 0);      // wave-uniform: rows past M add nothing to gamma / beta
-            const float4 xv = xv8[q];
-            const float mean = st8[q].x, rstd = st8[q].y;
-            float4 xh, gy;
-            float s1 = 0.f, s2 = 0.f;
-            xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-            gy = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-            s1 += gy.x + gy.y + gy.z + gy.w;
-            s2 += gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w;
-            dg.x += d.x * xh.x; dg.y += d.y * xh.y; dg.z += d.z * xh.z; dg.w += d.w * xh.w;
-            db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
-            xh8[q] = xh; gy8[q] = gy; s18[q] = s1; s28[q] = s2;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float u1[RM / 8], u2[RM / 8];
-#pragma unroll
-            for (int q = 0; q < RM / 8; ++q) { u1[q] = __shfl_xor(s18[q], o, 64); u2[q] = __shfl_xor(s28[q], o, 64); }
-#pragma unroll
-            for (int q = 0; q < RM / 8; ++q) { s18[q] += u1[q]; s28[q] += u2[q]; }
-        }
+        // per row ln_bwd_fast_kernel's statements (kzv_common.h ln_bwd_*; the rows' wave sums one after the other, as there)
 #pragma unroll
         for (int q = 0; q < RM / 8; ++q) {
             const int row = w * (RM / 8) + q, m = m0 + row;
@@ -707,11 +696,14 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
                 *(uint2*)(a1 + row * LDH + lane * 4) = make_uint2(0, 0);
                 continue;
             }
+            float4 d = d8[q];
+            if (p.resid) { const float4 r = rv8[q]; d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
             const float rstd = st8[q].y;
-            const float4 xh = xh8[q], gy = gy8[q];
-            const float m1 = s18[q] * invH, m2 = s28[q] * invH;
-            float4 o = make_float4(rstd * (gy.x - m1 - xh.x * m2), rstd * (gy.y - m1 - xh.y * m2),
-                                   rstd * (gy.z - m1 - xh.z * m2), rstd * (gy.w - m1 - xh.w * m2));
+            const LnBwdTerms t = ln_bwd_terms(d, xv8[q], gm, st8[q].x, rstd);
+            const float s1 = __fadd_rn(0.f, t.s1), s2 = __fadd_rn(0.f, t.s2);
+            ln_bwd_accum(dg, db, d, t);
+            const float m1 = __fmul_rn(wave_sum(s1), invH), m2 = __fmul_rn(wave_sum(s2), invH);
+            float4 o = ln_bwd_dx(t, m1, m2, rstd);
             *(float4*)(p.dsum + (int64_t)m * HD + lane * 4) = o;
             if (p.odrop.thr16) {
                 const unsigned e = (unsigned)m * (unsigned)HD + 4u * lane;
@@ -759,7 +751,13 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
             f32x4 acc[2][RT];
             if (pass + 1 < NP2) chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), wave_frags<2, 8>(p.wp2 + (int64_t)(pass + 1) * 65536, w), a1, LDH, lane, acc);
             else chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), nullptr, a1, LDH, lane, acc);
-            if constexpr (NP2 > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // gelu' (requested before the MFMAs): retired by hand, as above
+            if constexpr (NP2 > 1) {                              // gelu' (requested before the MFMAs): retired by hand
+                retire_loads();
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) pin(u[c][rt]);
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int n0 = 256 * pass + (w + 8 * c) * 16 + 4 * g;

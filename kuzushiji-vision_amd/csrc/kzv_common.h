@@ -47,6 +47,27 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- LayerNorm backward: the per-lane part of one row (4 columns) -----------------------------------------------------------------
+// Explicit roundings (no contraction left to the compiler's choice per context): ln_bwd_fast_kernel (layernorm.hip) and the decoder's
+// backward segments (decoder_chain.hip) carry the same row arithmetic and must produce the same bits.
+struct LnBwdTerms { float4 xh, gy; float s1, s2; };
+__device__ __forceinline__ LnBwdTerms ln_bwd_terms(const float4 d, const float4 xv, const float4 gm, float mean, float rstd) {
+    LnBwdTerms t;
+    t.xh = make_float4(__fmul_rn(__fsub_rn(xv.x, mean), rstd), __fmul_rn(__fsub_rn(xv.y, mean), rstd), __fmul_rn(__fsub_rn(xv.z, mean), rstd), __fmul_rn(__fsub_rn(xv.w, mean), rstd));
+    t.gy = make_float4(__fmul_rn(d.x, gm.x), __fmul_rn(d.y, gm.y), __fmul_rn(d.z, gm.z), __fmul_rn(d.w, gm.w));
+    t.s1 = __fadd_rn(__fadd_rn(__fadd_rn(t.gy.x, t.gy.y), t.gy.z), t.gy.w);
+    t.s2 = __fmaf_rn(t.gy.w, t.xh.w, __fmaf_rn(t.gy.z, t.xh.z, __fmaf_rn(t.gy.y, t.xh.y, __fmul_rn(t.gy.x, t.xh.x))));
+    return t;
+}
+__device__ __forceinline__ void ln_bwd_accum(float4& dg, float4& db, const float4 d, const LnBwdTerms& t) {      // gamma / beta partial sums
+    dg.x = __fmaf_rn(d.x, t.xh.x, dg.x); dg.y = __fmaf_rn(d.y, t.xh.y, dg.y); dg.z = __fmaf_rn(d.z, t.xh.z, dg.z); dg.w = __fmaf_rn(d.w, t.xh.w, dg.w);
+    db.x = __fadd_rn(db.x, d.x); db.y = __fadd_rn(db.y, d.y); db.z = __fadd_rn(db.z, d.z); db.w = __fadd_rn(db.w, d.w);
+}
+__device__ __forceinline__ float4 ln_bwd_dx(const LnBwdTerms& t, float m1, float m2, float rstd) {              // rstd * (gy - m1 - xh * m2)
+    return make_float4(__fmul_rn(rstd, __fmaf_rn(-t.xh.x, m2, __fsub_rn(t.gy.x, m1))), __fmul_rn(rstd, __fmaf_rn(-t.xh.y, m2, __fsub_rn(t.gy.y, m1))),
+                       __fmul_rn(rstd, __fmaf_rn(-t.xh.z, m2, __fsub_rn(t.gy.z, m1))), __fmul_rn(rstd, __fmaf_rn(-t.xh.w, m2, __fsub_rn(t.gy.w, m1))));
+}
+
 // ---- counter-based dropout bits ------------------------------------------------
 // One 32-bit hash per PAIR of elements; each element takes 16 bits and is KEPT iff bits >= thr16
 // (thr16 = round(p * 65536)), so P(drop) = thr16/65536.  The same (key, pair index) is recomputed in

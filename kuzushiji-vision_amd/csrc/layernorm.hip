@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const LnBwd p) {
         const bool has_dy = !(p.drop_first && row % p.seq == 0);
         const int drow = p.drop_first ? max(row - row / p.seq - 1, 0) : row;
         const float mean = b.mean, rstd = b.rstd;
-        float4 xh[NC], gy[NC];
+        LnBwdTerms tm[NC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -268,23 +268,18 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const LnBwd p) {
                 d.x *= drop_keep(b0, 0, p.thr16, p.inv_keep); d.y *= drop_keep(b0, 1, p.thr16, p.inv_keep);
                 d.z *= drop_keep(b1, 0, p.thr16, p.inv_keep); d.w *= drop_keep(b1, 1, p.thr16, p.inv_keep);
             }
-            const float4 xv = b.x[c], gm = gmr[c];
-            xh[c] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-            gy[c] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-            s1 += gy[c].x + gy[c].y + gy[c].z + gy[c].w;
-            s2 += gy[c].x * xh[c].x + gy[c].y * xh[c].y + gy[c].z * xh[c].z + gy[c].w * xh[c].w;
-            dg[c].x += d.x * xh[c].x; dg[c].y += d.y * xh[c].y; dg[c].z += d.z * xh[c].z; dg[c].w += d.w * xh[c].w;
-            db[c].x += d.x; db[c].y += d.y; db[c].z += d.z; db[c].w += d.w;
+            tm[c] = ln_bwd_terms(d, b.x[c], gmr[c], mean, rstd);      // kzv_common.h: the row arithmetic with explicit roundings
+            s1 = __fadd_rn(s1, tm[c].s1); s2 = __fadd_rn(s2, tm[c].s2);
+            ln_bwd_accum(dg[c], db[c], d, tm[c]);
         }
-        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+        const float m1 = __fmul_rn(wave_sum(s1), invH), m2 = __fmul_rn(wave_sum(s2), invH);
         float4* dxr = (float4*)(p.dx + (int64_t)row * p.H);
         float4 om[F8 ? NC : 1];
         float amax = 0.f, ssq = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int i = lane + c * 64;
-            float4 o = make_float4(rstd * (gy[c].x - m1 - xh[c].x * m2), rstd * (gy[c].y - m1 - xh[c].y * m2),
-                                   rstd * (gy[c].z - m1 - xh[c].z * m2), rstd * (gy[c].w - m1 - xh[c].w * m2));
+            float4 o = ln_bwd_dx(tm[c], m1, m2, rstd);
             if (ACC) { o.x += b.prev[c].x; o.y += b.prev[c].y; o.z += b.prev[c].z; o.w += b.prev[c].w; }
             dxr[i] = o;
             if (p.out16) {

@@ -58,8 +58,7 @@ def test_chains_equal_the_launch_per_operation_forward(tmp_path, B, Lh, train):
         dg2 = float((g1 - g2).abs().max())
         print(f", largest gradient difference {dg:.2e} (forward chains) / {dg2:.2e} (backward segments vs launches) of {sc:.2e}")
         assert dg < 1e-4 * sc                                   # same arithmetic, same dropout bits: differences are summation order at most
-        assert dg2 < 1e-4 * sc      # the segments: the launches' statements and rounding points; fp32 contraction / partial-sum order differ, and a last-bit
-                                    # difference of a LayerNorm gradient can move single bf16 operands of the next GEMM by one ulp (1e-5 of the scale seen)
+        assert dg2 < 1e-6 * sc      # the segments: the launches' arithmetic bit for bit (kzv_common.h ln_bwd_*); what differs is float-atomic order
 
 
 @pytest.mark.parametrize("B,Lh,train,vocab", [(5, 30, True, 4300), (3, 12, True, 100), (7, 23, False, 777), (70, 9, True, 4300)])
@@ -103,4 +102,36 @@ def test_chains_at_the_benchmark_decoder_geometry(tmp_path):
     dg2 = float((g1 - g2).abs().max())
     print(f"loss {l0:.6f} / {l1:.6f}, largest logit difference {dz:.2e}, largest gradient difference {dg:.2e} / {dg2:.2e} (backward segments) of {sc:.2e}")
     assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and dz < 1e-4 and dg < 1e-4 * sc
-    assert abs(l2 - l1) < 2e-6 * max(1.0, abs(l1)) and torch.equal(z1, z2) and dg2 < 1e-4 * sc
+    assert abs(l2 - l1) < 2e-6 * max(1.0, abs(l1)) and torch.equal(z1, z2) and dg2 < 1e-6 * sc
+
+
+def test_chains_with_more_workgroups_than_compute_units(tmp_path):
+    """256 sequences x 127 positions = 32,512 decoder rows = 508 workgroups of 64 rows on 256 CUs (the untrimmed benchmark step), the INPUT
+    changing from step to step: logits bit-identical to the launch-per-operation path in every step.  Rounds 3 - 4 failed this (found in
+    round 4's second session: tools/dev/r5_det3.py): the residual epilogue consumed registers whose loads -- issued early, some inside a
+    uniform branch -- had not landed, hipcc's own vmcnt wait being too lenient; 2 - 5 % of chain A's workgroups then added `beta` instead
+    of the LayerNorm output for 16 rows (logits off by 0.2), only once a launch had more workgroups than CUs (slower loads), and repeated
+    inputs hid nothing.  csrc/decoder_chain.hip now retires such loads by hand (retire_loads + pin)."""
+    cfg = dataclasses.replace(tiny_config(), dec_hidden=256, dec_heads=4, dec_ffn=768, dec_layers=4, max_pos=130)
+    lib = L.load()
+    d = build_decoder_dir(str(tmp_path / "dec"), cfg)
+    m = TrOCRModel(cfg.encoder_config_dict(), d, init_seed=9, load_tokenizer=False)
+    ins = []
+    for seed in (1, 2):
+        px, lab = synthetic_batch(cfg, 256, 128, seed=seed, min_chars=1, max_chars=126)
+        ins.append((torch.from_numpy(px).cuda(), torch.from_numpy(lab).cuda()))
+    m.train()
+
+    def logits(i, mode):
+        L.check(lib.kzv_set_dec_chain(mode), "mode")
+        _, z = m.forward_loss(ins[i][0], ins[i][1], want_logits=True, seed=11)
+        torch.cuda.synchronize()
+        return z.clone()
+
+    ref = [logits(0, 0), logits(1, 0)]
+    assert ref[0].shape[0] * ref[0].shape[1] > 256 * 64
+    for mode in (1, 2):
+        for i in (0, 1, 1, 0, 1, 0):
+            z = logits(i, mode)
+            bad = int(((z - ref[i]).abs().amax(-1) > 0).sum())
+            assert bad == 0, f"mode {mode}, input {i}: {bad} rows differ from the launch-per-operation path"
