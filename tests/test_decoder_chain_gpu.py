@@ -135,3 +135,34 @@ def test_chains_with_more_workgroups_than_compute_units(tmp_path):
             z = logits(i, mode)
             bad = int(((z - ref[i]).abs().amax(-1) > 0).sum())
             assert bad == 0, f"mode {mode}, input {i}: {bad} rows differ from the launch-per-operation path"
+
+    # the same for the backward (the segments and the row-panel input gradients run 508 workgroups too): every gradient against mode 0
+    def grads(i, mode):
+        L.check(lib.kzv_set_dec_chain(mode), "mode")
+        m.zero_grad()
+        m.forward_loss(ins[i][0], ins[i][1], want_logits=True, seed=11)
+        m.backward()
+        torch.cuda.synchronize()
+        return m.flat_grads.clone()
+
+    gref = [grads(0, 0), grads(1, 0)]
+    for mode in (1, 2):
+        for i in (0, 1, 0):
+            g = grads(i, mode)
+            sc = float(gref[i].abs().max()); dg = float((g - gref[i]).abs().max())
+            assert dg < 1e-5 * sc, f"mode {mode}, input {i}: largest gradient difference {dg:.2e} of {sc:.2e}"
+
+    # ... and the one-launch LM head + cross-entropy (508 workgroups as well) against the head GEMM + ce_kernel, logits not returned
+    def step(i, head):
+        L.check(lib.kzv_set_dec_chain(2), "mode"); L.check(lib.kzv_set_head_ce(head), "head")
+        m.zero_grad()
+        loss, _ = m.forward_loss(ins[i][0], ins[i][1], want_logits=False, seed=11)
+        m.backward()
+        torch.cuda.synchronize()
+        return float(loss), m.flat_grads.clone()
+
+    m.trim_padding = False
+    for i in (0, 1, 0):
+        (l0, g0), (l1, g1) = step(i, 0), step(i, 1)
+        sc = float(g0.abs().max()); dg = float((g0 - g1).abs().max())
+        assert abs(l0 - l1) < 2e-6 * max(1.0, abs(l0)) and dg < 2e-3 * sc, (i, l0, l1, dg, sc)      # bf16 dlogits on both sides (see the head test above)
