@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) { gem
 
 // Grouped launch: several independent weight gradients (e.g. the six of one decoder layer, 4..12 tiles of 128x128 each)
 // share ONE grid, so the 256 CUs x 2 resident workgroups are filled in a single round instead of six part-filled ones.
-constexpr int TN_GROUP_MAX = 8;
+constexpr int TN_GROUP_MAX = 40;     // 88-byte descriptors in the kernel arguments (4 KiB): the 36 weight gradients of a six-layer decoder in one grid
 struct TnGroup { TnParams p[TN_GROUP_MAX]; int start[TN_GROUP_MAX + 1]; int n; };
 __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(const TnGroup g) {
     int i = 0;
@@ -610,7 +610,11 @@ int kzv_gemm_tn_group(const kzv_gemm_tn_args* a, int n, hipStream_t s) {
     int blocks = 0;
     for (int i = 0; i < g.n; ++i) {
         const int tiles = ((g.p[i].N + 127) / 128) * ((g.p[i].K + 127) / 128);
-        int share = (int)((int64_t)tn_target() * tiles / tiles_total);
+        // one resident round (512 workgroups) for the small groups; a group with more tiles than that round's half (the 36 weight
+        // gradients of the decoder's layers: 288 tiles) takes two: 3 token splits of 80 stages, 261 us against 335 with one split per
+        // tile and 348 for six launches of ten splits (tools/dev/r5_tnblocks.sh)
+        const int target = tiles_total >= 256 ? 2 * tn_target() : tn_target();
+        int share = (int)((int64_t)target * tiles / tiles_total);
         if (share < tiles) share = tiles;
         g.start[i] = blocks;
         blocks += tn_plan(g.p[i], share);

@@ -36,6 +36,8 @@ struct EncAct {
 struct DecAct {
     float *s1, *x1, *s2, *x2, *s3, *x3, *st1, *st2, *st3, *lse_sa, *lse_ca;
     bf16_t *qkv, *ctx, *x1h, *cq, *cctx, *x2h, *pre, *act, *x3h;
+    // backward (segment path): this layer's six "dY" operands stay alive until ONE grouped weight-gradient launch behind the last layer
+    bf16_t *g_dy = nullptr, *g_dbig = nullptr, *g_dy2 = nullptr, *g_dq = nullptr, *g_dy3 = nullptr, *g_dqkv = nullptr;
 };
 
 }  // namespace
@@ -320,6 +322,12 @@ int64_t plan(kzv_model* m, char* base, int B, int L) {
     m->dy_d2 = b.take<bf16_t>(Md * Hd); m->dy_d3 = b.take<bf16_t>(Md * Hd);
     m->dy_d = b.take<bf16_t>(Md * Hd); m->dbig_d = b.take<bf16_t>(Md * Fd); m->dqkv_d = b.take<bf16_t>(Md * 3 * Hd);
     m->dctx_d = b.take<bf16_t>(Md * Hd); m->dq_d = b.take<bf16_t>(Md * Hd); m->dhln = b.take<bf16_t>(Md * Hd);
+    if (kzv_dec_chain_supported(Hd, Fd))        // the segment path's per-layer gradient operands (2.8 KB per decoder row and layer)
+        for (int i = 0; i < m->Ld; ++i) {
+            DecAct& a = m->da[i];
+            a.g_dy = b.take<bf16_t>(Md * Hd); a.g_dbig = b.take<bf16_t>(Md * Fd); a.g_dy2 = b.take<bf16_t>(Md * Hd);
+            a.g_dq = b.take<bf16_t>(Md * Hd); a.g_dy3 = b.take<bf16_t>(Md * Hd); a.g_dqkv = b.take<bf16_t>(Md * 3 * Hd);
+        }
     (void)weights_end;
     return align_up(b.off, 256);
 }
@@ -385,7 +393,9 @@ int wgrad_batch(kzv_model* m, int cls, hipStream_t s, const bf16_t* dY, int64_t 
                 int N, int K, int n_store, float* dbias);
 int wgrad_flush(kzv_model* m, hipStream_t s) {
     if (m->wbatch.empty()) return KZV_OK;
-    const int rc = kzv_gemm_tn_group(m->wbatch.data(), (int)m->wbatch.size(), s);
+    int rc = KZV_OK;
+    for (size_t i = 0; i < m->wbatch.size() && rc == KZV_OK; i += 36)        // <= 36 problems per grid (gemm.hip TN_GROUP_MAX = 40)
+        rc = kzv_gemm_tn_group(m->wbatch.data() + i, (int)std::min<size_t>(36, m->wbatch.size() - i), s);
     m->wbatch.clear();
     return rc;
 }
@@ -645,30 +655,33 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
         if (segs) {
             const float hp = dp(m, c.dec_hidden_dropout);
             const bool top = i == m->Ld - 1;
+            // every "dY" of this layer goes to the layer's own buffers: the 6 x Ld weight gradients are ONE grouped launch behind the loop
+            // (36 problems, 288 tiles of 128 x 128 over all tokens instead of six part-filled grids of ten token splits and their atomics)
             // [head dense | the layer above's qkv] -> LN3 -> fc2 (gelu')
-            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{top ? m->dy_d : m->dqkv_d, top ? Hd : 3 * Hd, tp(top ? m->Ld : i + 1, 0), top ? nullptr : m->dsum_d,
-                                                 a.s3, a.st3, P + d.ln3w, G + d.ln3w, G + d.ln3b, m->dsum_d, m->dy_d, hp, key(m, site + 4),
-                                                 tp(i, 6 * HHd + FHd), a.pre, m->dbig_d, Md}, s));
-            KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
-            KZV_TRY(wgrad_batch(m, CLS_DBIG, s, m->dbig_d, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
+            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{top ? m->dy_d : m->da[i + 1].g_dqkv, top ? Hd : 3 * Hd, tp(top ? m->Ld : i + 1, 0), top ? nullptr : m->dsum_d,
+                                                 a.s3, a.st3, P + d.ln3w, G + d.ln3w, G + d.ln3b, m->dsum_d, a.g_dy, hp, key(m, site + 4),
+                                                 tp(i, 6 * HHd + FHd), a.pre, a.g_dbig, Md}, s));
+            KZV_TRY(wgrad_batch(m, CLS_DY, s, a.g_dy, Hd, a.act, Fd, G + d.fc2w, Md, Hd, Fd, Hd, G + d.fc2b));
+            KZV_TRY(wgrad_batch(m, CLS_DBIG, s, a.g_dbig, Fd, a.x2h, Hd, G + d.fc1w, Md, Fd, Hd, Fd, G + d.fc1b));
             // fc1 -> LN2 -> cross-attention output projection
-            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{m->dbig_d, Fd, tp(i, 6 * HHd), m->dsum_d, a.s2, a.st2, P + d.ln2w, G + d.ln2w, G + d.ln2b, m->dsum_d, m->dy_d2,
+            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{a.g_dbig, Fd, tp(i, 6 * HHd), m->dsum_d, a.s2, a.st2, P + d.ln2w, G + d.ln2w, G + d.ln2b, m->dsum_d, a.g_dy2,
                                                  hp, key(m, site + 3), tp(i, 5 * HHd), nullptr, m->dctx_d, Md}, s));
-            KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d2, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
+            KZV_TRY(wgrad_batch(m, CLS_DY, s, a.g_dy2, Hd, a.cctx, Hd, G + d.cow, Md, Hd, Hd, Hd, G + d.cob));
             KZV_TRY(attn(m, true, 0, a.cq, Hd, m->crosskv + (int64_t)i * 2 * Hd, m->crosskv + (int64_t)i * 2 * Hd + Hd, CK, a.cctx, Hd, a.lse_ca,
-                         m->dctx_d, m->dq_d, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->npa,
+                         m->dctx_d, a.g_dq, m->dckv + (int64_t)i * 2 * Hd, m->dckv + (int64_t)i * 2 * Hd + Hd, c.dec_heads, T, m->npa,
                          dp(m, c.dec_attn_dropout), key(m, site + 2), s));
-            KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dq_d, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
+            KZV_TRY(wgrad_batch(m, CLS_MISC, s, a.g_dq, Hd, a.x1h, Hd, G + d.cqw, Md, Hd, Hd, Hd, G + d.cqb));
             // cross-attention query -> LN1 -> self-attention output projection
-            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{m->dq_d, Hd, tp(i, 4 * HHd), m->dsum_d, a.s1, a.st1, P + d.ln1w, G + d.ln1w, G + d.ln1b, m->dsum_d, m->dy_d3,
+            KZV_TRY(kzv_dec_bwd_seg(KzvDecBwdSeg{a.g_dq, Hd, tp(i, 4 * HHd), m->dsum_d, a.s1, a.st1, P + d.ln1w, G + d.ln1w, G + d.ln1b, m->dsum_d, a.g_dy3,
                                                  hp, key(m, site + 1), tp(i, 3 * HHd), nullptr, m->dctx_d, Md}, s));
-            KZV_TRY(wgrad_batch(m, CLS_DY, s, m->dy_d3, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
-            KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, m->dqkv_d, m->dqkv_d + Hd,
-                         m->dqkv_d + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
-            KZV_TRY(wgrad_batch(m, CLS_DQKV, s, m->dqkv_d, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
-            if (i == 0)      // the bottom layer's qkv feeds the embedding LayerNorm: its own launch (a lower layer's first segment takes it otherwise)
-                KZV_TRY(gemm(m->dqkv_d, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
-            KZV_TRY(wgrad_flush(m, s));
+            KZV_TRY(wgrad_batch(m, CLS_DY, s, a.g_dy3, Hd, a.ctx, Hd, G + d.ow, Md, Hd, Hd, Hd, G + d.ob));
+            KZV_TRY(attn(m, true, 1, a.qkv, 3 * Hd, a.qkv + Hd, a.qkv + 2 * Hd, 3 * Hd, a.ctx, Hd, a.lse_sa, m->dctx_d, a.g_dqkv, a.g_dqkv + Hd,
+                         a.g_dqkv + 2 * Hd, c.dec_heads, T, T, dp(m, c.dec_attn_dropout), key(m, site), s));
+            KZV_TRY(wgrad_batch(m, CLS_DQKV, s, a.g_dqkv, 3 * Hd, xh, Hd, G + d.qkvw, Md, 3 * Hd, Hd, 3 * Hd, G + d.qkvb));
+            if (i == 0) {    // the bottom layer's qkv feeds the embedding LayerNorm: its own launch (a lower layer's first segment takes it otherwise)
+                KZV_TRY(gemm(a.g_dqkv, 3 * Hd, m->w_dqkv[i], true, Md, Hd, 3 * Hd, Hd, nullptr, m->dx_d, Hd, KZV_EPI_RESID, s, m->dsum_d));
+                KZV_TRY(wgrad_flush(m, s));      // all 6 x Ld weight gradients of the decoder layers
+            }
             continue;
         }
         // FFN block: x3 = LN(s3), s3 = x2 + drop(fc2(gelu(fc1(x2))))
