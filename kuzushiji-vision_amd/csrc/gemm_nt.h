@@ -25,6 +25,8 @@ struct NtParams {
 // r4 = the residual (RESID), u2 = the saved GELU derivative as 4 bf16 (DGELU), both loaded by the caller.
 // Outputs are written once and next read by a later kernel: stream them past L2 (global_store ... nt) so the
 // operand panels stay cached and no dirty backlog waits for the end-of-kernel write-back (-3..4 % on the ViT GEMMs).
+// Re-tested per epilogue in round 4 (tools/dev/r5_stores.sh, same-box alternations): plain stores for the fc1 activation -0.5 % step, for
+// the bf16 outputs -0.1 %, for the DGELU output +-0; for the RESID output (the residual stream) +0.3 %: that one is stored plainly.
 #ifndef KZV_NT_PLAIN_STORES
 __device__ __forceinline__ void nt_st(uint2* dst, const uint2& v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -61,7 +63,12 @@ __device__ __forceinline__ void nt_emit(const NtParams& p, int m, int n0, float 
             v[2] *= drop_keep(b1, 0, p.drop_thr16, p.drop_inv_keep);
             v[3] *= drop_keep(b1, 1, p.drop_thr16, p.drop_inv_keep);
         }
+#ifndef KZV_RESID_NT       // the residual stream is read again at once (the LayerNorm behind this GEMM, then the next residual add): a PLAIN store leaves it in
+                           // L2 / the Infinity Cache: step 31.02 -> 30.93 ms, family 0.386 -> 0.388 over four same-box alternations (round 4, tools/dev/ab_build.sh)
+        *(float4*)((float*)p.C + (int64_t)m * p.ldc + n0) = make_float4(v[0] + r4.x, v[1] + r4.y, v[2] + r4.z, v[3] + r4.w);
+#else
         nt_st((float4*)((float*)p.C + (int64_t)m * p.ldc + n0), make_float4(v[0] + r4.x, v[1] + r4.y, v[2] + r4.z, v[3] + r4.w));
+#endif
     } else if (EPI == KZV_EPI_DGELU) {
         v[0] *= bf2f((bf16_t)(u2.x & 0xffff));          // u2 = gelu'(pre-activation), stored by the forward GELU epilogue
         v[1] *= bf2f((bf16_t)(u2.x >> 16));
