@@ -44,7 +44,8 @@ __device__ __forceinline__ void fill_window(bf16x8 (&R)[WIN], const char* wb, in
     for (int i = 0; i < WIN; ++i) R[i] = ld_frag<CB, KS>(wb, wo, i);
 }
 // acc[c][rt][r] = sum_k W[n][k] * a[m][k],  m = 16 rt + (lane & 15),  n = (w + 8 c) * 16 + 4 (lane >> 4) + r
-template <int CB, int KS, int NCB, int NKS>
+// NEXT (compile time): refill the window from `next` behind the last fragments -- no run-time branch around a load (see pin)
+template <int CB, int KS, int NCB, int NKS, bool NEXT>
 __device__ __forceinline__ void chain_gemm(bf16x8 (&R)[WIN], const char* wb, const char* next, const bf16_t* a_lds, int lda, int lane, f32x4 (&acc)[CB][RT]) {
     constexpr int F = CB * KS;
     static_assert(F % WIN == 0 && NCB * NKS >= WIN, "chain_gemm: window");
@@ -66,7 +67,7 @@ __device__ __forceinline__ void chain_gemm(bf16x8 (&R)[WIN], const char* wb, con
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R[i % WIN], fa[rt], acc[c][rt], 0, 0, 0);
         if (i + WIN < F) R[i % WIN] = ld_frag<CB, KS>(wb, wo, i + WIN);
-        else if (next) R[i % WIN] = ld_frag<NCB, NKS>(next, wo, i + WIN - F);
+        else if constexpr (NEXT) R[i % WIN] = ld_frag<NCB, NKS>(next, wo, i + WIN - F);
     }
 }
 
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512) void dec_chain_a_kernel(const SegA p) {
     {
         const int lane = opaque(lane0);
         f32x4 acc[2][RT];
-        chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wo, w), wave_frags<2, 8>(p.wcq, w), a1, LDH, lane, acc);
+        chain_gemm<2, 8, 2, 8, true>(R, wave_frags<2, 8>(p.wo, w), wave_frags<2, 8>(p.wcq, w), a1, LDH, lane, acc);
         resid_epilogue(acc, p.bo, p.xres, rr, p.drop, ssum, m0, p.M, w, lane);
     }
     wg_barrier();                // every wave has read the ctx tile and written its part of the sum tile
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(512) void dec_chain_a_kernel(const SegA p) {
     {
         const int lane = opaque(lane0);
         f32x4 acc[2][RT];
-        chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wcq, w), nullptr, a1, LDH, lane, acc);
+        chain_gemm<2, 8, 2, 8, false>(R, wave_frags<2, 8>(p.wcq, w), nullptr, a1, LDH, lane, acc);
         bf16_to_lds<2>(acc, p.bcq, (bf16_t*)ssum, LDH, w, lane);
     }
     wg_barrier();
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     {   // s2 = drop(cctx Wco^T + b) + x1
         const int lane = opaque(lane0);
         f32x4 acc[2][RT];
-        chain_gemm<2, 8, 6, 8>(R, wave_frags<2, 8>(p.wco, w), wave_frags<6, 8>(p.wfc1, w), a1, LDH, lane, acc);
+        chain_gemm<2, 8, 6, 8, true>(R, wave_frags<2, 8>(p.wco, w), wave_frags<6, 8>(p.wfc1, w), a1, LDH, lane, acc);
         resid_epilogue(acc, p.bco, p.x1, rr, p.drop3, ssum, m0, p.M, w, lane);
     }
     wg_barrier();
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
         // passes of 256 columns through the operand tile, which the MFMAs no longer read
         const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
         f32x4 acc[6][RT];
-        chain_gemm<6, 8, 2, 24>(R, wave_frags<6, 8>(p.wfc1, w), wave_frags<2, 24>(p.wfc2, w), a1, LDH, lane, acc);
+        chain_gemm<6, 8, 2, 24, true>(R, wave_frags<6, 8>(p.wfc1, w), wave_frags<2, 24>(p.wfc2, w), a1, LDH, lane, acc);
         wg_barrier();            // every wave has read x2h
         CH_STAMP(4);
 #pragma unroll
@@ -359,8 +360,8 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     resid_prefetch(res2, rr, m0, p.M, w, opaque(lane0));
     {   // s3 = drop(act Wfc2^T + b) + x2
         const int lane = opaque(lane0);
-        if (p.wqkv) chain_gemm<2, 24, 6, 8>(R, wave_frags<2, 24>(p.wfc2, w), wave_frags<6, 8>(p.wqkv, w), a2, LDW, lane, acc3);
-        else chain_gemm<2, 24, 6, 8>(R, wave_frags<2, 24>(p.wfc2, w), nullptr, a2, LDW, lane, acc3);
+        if (p.wqkv) chain_gemm<2, 24, 6, 8, true>(R, wave_frags<2, 24>(p.wfc2, w), wave_frags<6, 8>(p.wqkv, w), a2, LDW, lane, acc3);
+        else chain_gemm<2, 24, 6, 8, false>(R, wave_frags<2, 24>(p.wfc2, w), nullptr, a2, LDW, lane, acc3);
     }
     wg_barrier();                // every wave has read the activation tile: the sum tile (same memory) may be written
     CH_STAMP(7);
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
     {   // the next layer's q | k | v = x3 Wqkv^T + b, staged through the (dead) activation tile
         const int lane = opaque(lane0);
         f32x4 acc[6][RT];
-        chain_gemm<6, 8, 2, 8>(R, wave_frags<6, 8>(p.wqkv, w), nullptr, a1, LDH, lane, acc);
+        chain_gemm<6, 8, 2, 8, false>(R, wave_frags<6, 8>(p.wqkv, w), nullptr, a1, LDH, lane, acc);
         bf16_to_lds<6>(acc, p.bqkv, a2, LDW, w, lane);
     }
     wg_barrier();
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
     for (int j = 0; j < p.nch; ++j) {
         f32x4 acc[2][RT];
         const bf16_t* nextw = p.wp + (int64_t)(j + 1 < p.nch ? j + 1 : 0) * 65536;          // the last chunk prefetches pass 2's first
-        chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(nextw, w), a1, LDH, lane, acc);
+        chain_gemm<2, 8, 2, 8, true>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(nextw, w), a1, LDH, lane, acc);
         float v[2][RT][4];
         chunk_logits(j, acc, v);
 #pragma unroll
@@ -501,8 +502,8 @@ __global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
 #pragma unroll 1
     for (int j = 0; j < p.nch; ++j) {
         f32x4 acc[2][RT];
-        if (j + 1 < p.nch) chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(p.wp + (int64_t)(j + 1) * 65536, w), a1, LDH, lane, acc);
-        else chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), nullptr, a1, LDH, lane, acc);
+        if (j + 1 < p.nch) chain_gemm<2, 8, 2, 8, true>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(p.wp + (int64_t)(j + 1) * 65536, w), a1, LDH, lane, acc);
+        else chain_gemm<2, 8, 2, 8, false>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), nullptr, a1, LDH, lane, acc);
         float v[2][RT][4];
         chunk_logits(j, acc, v);
 #pragma unroll
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(512) void dec_lin_kernel(const DecLin p) {
     wg_barrier();
     const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
     f32x4 acc[CB][RT];
-    chain_gemm<CB, KS, CB, KS>(R, wave_frags<CB, KS>(p.wp, w), nullptr, at, LDA, lane, acc);
+    chain_gemm<CB, KS, CB, KS, false>(R, wave_frags<CB, KS>(p.wp, w), nullptr, at, LDA, lane, acc);
     wg_barrier();                                                 // every wave has read the operand tile: it becomes the output tile
     if constexpr (EPI == DL_RESID) {
         float* ot = (float*)smem;                                 // [RM][LDO32] fp32
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
     {
         const int lane = opaque(lane0), l15 = lane & 15, g = lane >> 4;
         f32x4 acc[2][RT];
-        chain_gemm<2, KS1, 2, 8>(R, wave_frags<2, KS1>(p.wp1, w), wave_frags<2, 8>(p.wp2, w), at, LDA, lane, acc);
+        chain_gemm<2, KS1, 2, 8, true>(R, wave_frags<2, KS1>(p.wp1, w), wave_frags<2, 8>(p.wp2, w), at, LDA, lane, acc);
         wg_barrier();                                             // every wave has read the operand rows: the fp32 tile takes their place
         SEG_STAMP(18);
 #pragma unroll
@@ -749,8 +750,8 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
                     }
             }
             f32x4 acc[2][RT];
-            if (pass + 1 < NP2) chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), wave_frags<2, 8>(p.wp2 + (int64_t)(pass + 1) * 65536, w), a1, LDH, lane, acc);
-            else chain_gemm<2, 8, 2, 8>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), nullptr, a1, LDH, lane, acc);
+            if (pass + 1 < NP2) chain_gemm<2, 8, 2, 8, true>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), wave_frags<2, 8>(p.wp2 + (int64_t)(pass + 1) * 65536, w), a1, LDH, lane, acc);
+            else chain_gemm<2, 8, 2, 8, false>(R, wave_frags<2, 8>(p.wp2 + (int64_t)pass * 65536, w), nullptr, a1, LDH, lane, acc);
             if constexpr (NP2 > 1) {                              // gelu' (requested before the MFMAs): retired by hand
                 retire_loads();
 #pragma unroll

@@ -165,4 +165,5 @@ def test_chains_with_more_workgroups_than_compute_units(tmp_path):
     for i in (0, 1, 0):
         (l0, g0), (l1, g1) = step(i, 0), step(i, 1)
         sc = float(g0.abs().max()); dg = float((g0 - g1).abs().max())
-        assert abs(l0 - l1) < 2e-6 * max(1.0, abs(l0)) and dg < 2e-3 * sc, (i, l0, l1, dg, sc)      # bf16 dlogits on both sides (see the head test above)
+        # the loss is a float-atomic sum over 32 k rows (508 workgroups / 32 k ce_kernel rows in another order); bf16 dlogits on both sides (see the head test above)
+        assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and dg < 2e-3 * sc, (i, l0, l1, dg, sc)
