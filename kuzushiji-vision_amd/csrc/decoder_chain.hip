@@ -398,7 +398,9 @@ __global__ __launch_bounds__(512) void dec_chain_b_kernel(const SegB p) {
 struct HeadCE {
     const bf16_t* x; const bf16_t* wp; const float* bias; const int64_t* labels; const float* count; float* loss; bf16_t* dlogits;
     int M, L, T, V, Vp, nch, pad;
+    const bf16_t* wpt; bf16_t* dh;      // optional: dh[M, 256] = dlogits . W (the head's input gradient), wpt = W^T [256, 256 nch] in fragment order
 };
+template <bool DH>
 __global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* a1 = (bf16_t*)smem;                                   // [RM][LDH] the rows' operand tile
@@ -499,11 +501,30 @@ __global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) ls[rt] = lse_s[rt * 16 + l15];
     // ---- pass 2 ----
+    // With wpt / dh the head's input gradient rides along: dh = dlogits . W accumulates chunk by chunk from the staged dlogits tile (the
+    // launch it replaces read the 134 MB of dlogits back: 92 us in the step), the window alternating between the two weight streams.
+    constexpr bool with_dh = DH;                                               // compile time: no run-time branch around a load (see pin)
+    const int KSV = p.nch * 8;                                                 // 32-deep steps of the vocabulary in the transposed pack
+    const unsigned wo = (unsigned)lane * 16u;
+    auto tfrag = [&](int j, int i) -> bf16x8 {                                 // fragment i = (vocabulary step 8 j + i / 2, hidden column block w + 8 (i % 2))
+        return *(const bf16x8*)((const char*)p.wpt + ((int64_t)(w + 8 * (i & 1)) * KSV + 8 * j + (i >> 1)) * 1024 + wo);
+    };
+    f32x4 acc2[2][RT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc2[c][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int j = 0; j < p.nch; ++j) {
         f32x4 acc[2][RT];
-        if (j + 1 < p.nch) chain_gemm<2, 8, 2, 8, true>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(p.wp + (int64_t)(j + 1) * 65536, w), a1, LDH, lane, acc);
-        else chain_gemm<2, 8, 2, 8, false>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), nullptr, a1, LDH, lane, acc);
+        if constexpr (with_dh) {
+            chain_gemm<2, 8, 2, 8, false>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), nullptr, a1, LDH, lane, acc);
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) R[i] = tfrag(j, i);                  // in flight under the softmax arithmetic below
+        } else {
+            if (j + 1 < p.nch) chain_gemm<2, 8, 2, 8, true>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), wave_frags<2, 8>(p.wp + (int64_t)(j + 1) * 65536, w), a1, LDH, lane, acc);
+            else chain_gemm<2, 8, 2, 8, false>(R, wave_frags<2, 8>(p.wp + (int64_t)j * 65536, w), nullptr, a1, LDH, lane, acc);
+        }
         float v[2][RT][4];
         chunk_logits(j, acc, v);
 #pragma unroll
@@ -527,7 +548,34 @@ __global__ __launch_bounds__(512) void head_ce_kernel(const HeadCE p) {
                 if (m0 + row < p.M && ch < pieces) *(uint4*)(p.dlogits + (int64_t)(m0 + row) * p.Vp + j * 256 + ch * 8) = *(const uint4*)(stage + row * LDH + ch * 8);
             }
         }
+        if constexpr (with_dh) {                          // acc2 += (this chunk of dlogits) . W^T fragments; then the window goes back to the forward stream
+            const bf16_t* ap = stage + l15 * LDH + g * 8;
+            bf16x8 fa[RT];
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                if ((i & 1) == 0) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) fa[rt] = *(const bf16x8*)(ap + rt * 16 * LDH + (i >> 1) * 32);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc2[i & 1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R[i], fa[rt], acc2[i & 1][rt], 0, 0, 0);
+            }
+            const int jn = j + 1 < p.nch ? j + 1 : 0;     // (the last refill is unused: no branch around the loads)
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) R[i] = ld_frag<2, 8>(wave_frags<2, 8>(p.wp + (int64_t)jn * 65536, w), wo, i);
+        }
         wg_barrier();
+    }
+    if constexpr (with_dh) {                              // dh rows out through the stage tile (bf16, as the GEMM epilogue rounded them)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int nl = (w + 8 * c) * 16 + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                *(uint2*)(stage + (rt * 16 + l15) * LDH + nl) = make_uint2(pack_bf2(acc2[c][rt][0], acc2[c][rt][1]), pack_bf2(acc2[c][rt][2], acc2[c][rt][3]));
+        }
+        wg_barrier();
+        rows_out<32>(stage, LDH, p.dh, HD, m0, p.M, opaque(tid));
     }
 }
 
@@ -781,8 +829,8 @@ __global__ __launch_bounds__(512) void dec_bwd_seg_kernel(const SegBwd p) {
 }
 
 // every decoder weight of the model -> fragment order, one launch
-struct PackDesc { const uint4* src; uint4* dst; int N, K, t0, n_valid; };
-constexpr int PACK_PER_LAUNCH = 96;        // 32-byte descriptors in the kernel argument block (4 KiB limit)
+struct PackDesc { const uint4* src; uint4* dst; int N, K, t0, n_valid, ld, k_valid; };
+constexpr int PACK_PER_LAUNCH = 96;        // 40-byte descriptors in the kernel argument block (4 KiB limit)
 struct PackTable { PackDesc d[PACK_PER_LAUNCH]; int n; };
 __global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -792,8 +840,8 @@ __global__ void pack_frag_multi_kernel(const PackTable tab, int total) {
     const PackDesc& d = tab.d[k];
     const int u = t - d.t0, lane = u & 63, f = u >> 6, KS = d.K / 32;
     const int nb = f / KS, ks = f - nb * KS;
-    const int row = nb * 16 + (lane & 15);                      // rows beyond n_valid (the vocabulary's padding) pack as zeros
-    d.dst[u] = row < d.n_valid ? d.src[((int64_t)row * d.K + ks * 32 + (lane >> 4) * 8) / 8] : make_uint4(0, 0, 0, 0);
+    const int row = nb * 16 + (lane & 15), col = ks * 32 + (lane >> 4) * 8;      // rows beyond n_valid / columns beyond k_valid (the vocabulary's padding) pack as zeros
+    d.dst[u] = (row < d.n_valid && col < d.k_valid) ? d.src[((int64_t)row * d.ld + col) / 8] : make_uint4(0, 0, 0, 0);
 }
 
 }  // namespace
@@ -885,10 +933,16 @@ int kzv_head_ce(const KzvHeadCE& a, hipStream_t s) {
     HeadCE p;
     p.x = a.x; p.wp = a.wp; p.bias = a.bias; p.labels = a.labels; p.count = a.count; p.loss = a.loss; p.dlogits = a.dlogits;
     p.M = a.M; p.L = a.L; p.T = a.T; p.V = a.V; p.Vp = a.Vp; p.nch = (a.V + 255) / 256; p.pad = a.pad;
+    p.wpt = (a.dlogits && a.dh) ? a.wpt : nullptr; p.dh = a.dh;
     constexpr int LDS_H = 2 * LDS_A1 + RM * 64 * 4 + RM * 4 * 3;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)head_ce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H); attr_done = true; }
-    hipLaunchKernelGGL(head_ce_kernel, dim3((a.M + RM - 1) / RM), dim3(512), LDS_H, s, p);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)head_ce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H);
+        (void)hipFuncSetAttribute((const void*)head_ce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H);
+        attr_done = true;
+    }
+    if (p.wpt) hipLaunchKernelGGL(head_ce_kernel<true>, dim3((a.M + RM - 1) / RM), dim3(512), LDS_H, s, p);
+    else hipLaunchKernelGGL(head_ce_kernel<false>, dim3((a.M + RM - 1) / RM), dim3(512), LDS_H, s, p);
     return kzv_check_launch("head_ce");
 }
 
@@ -901,7 +955,8 @@ int kzv_pack_frag_multi(const KzvPackJob* jobs, int n, hipStream_t s) {
         for (int i = 0; i < cnt; ++i) {
             const KzvPackJob& jb = jobs[j0 + i];
             if (jb.N % 16 || jb.K % 32) return kzv_fail(KZV_E_ARG, "pack_frag_multi: N %% 16, K %% 32");
-            tab.d[i] = PackDesc{(const uint4*)jb.src, (uint4*)jb.dst, jb.N, jb.K, total, jb.n_valid > 0 ? jb.n_valid : jb.N};
+            if (jb.ld % 8 || jb.k_valid % 8) return kzv_fail(KZV_E_ARG, "pack_frag_multi: ld %% 8, k_valid %% 8");
+            tab.d[i] = PackDesc{(const uint4*)jb.src, (uint4*)jb.dst, jb.N, jb.K, total, jb.n_valid > 0 ? jb.n_valid : jb.N, jb.ld > 0 ? jb.ld : jb.K, jb.k_valid > 0 ? jb.k_valid : jb.K};
             total += jb.N * jb.K / 8;
         }
         tab.n = cnt;

@@ -121,11 +121,13 @@ struct KzvDecChainB {          // s2 = drop(cctx Wco^T + b) + x1; x2 = LN2(s2); 
 int kzv_dec_chain_supported(int Hd, int Fd);
 int kzv_dec_chain_a(const KzvDecChainA& a, hipStream_t s);
 int kzv_dec_chain_b(const KzvDecChainB& a, hipStream_t s);
-struct KzvPackJob { const bf16_t* src; bf16_t* dst; int N, K; int n_valid = 0; };      // rows >= n_valid (> 0) pack as zeros
+struct KzvPackJob { const bf16_t* src; bf16_t* dst; int N, K; int n_valid = 0; int ld = 0; int k_valid = 0; };      // rows >= n_valid / columns >= k_valid (> 0) pack as zeros; ld: source row stride (0 = K)
 // LM head + cross-entropy in one launch (decoder_chain.hip): x = the head's LayerNorm output [M, 256] bf16, wp = the tied weight in
 // fragment order (ceil(V / 256) * 256 rows, zeros beyond V), labels int64 [B, L] (row m = b * T + t scores labels[b][t + 1]), count = the
 // number of scored rows (device), loss accumulated (+=), dlogits bf16 [M, Vp] or null
-struct KzvHeadCE { const bf16_t* x; const bf16_t* wp; const float* bias; const int64_t* labels; const float* count; float* loss; bf16_t* dlogits; int M, L, T, V, Vp, pad; };
+struct KzvHeadCE { const bf16_t* x; const bf16_t* wp; const float* bias; const int64_t* labels; const float* count; float* loss; bf16_t* dlogits; int M, L, T, V, Vp, pad;
+                   // optional (with dlogits): dh[M, 256] = dlogits . W, the head's input gradient, from wpt = W^T [256, ceil(V / 256) * 256] in fragment order
+                   const bf16_t* wpt = nullptr; bf16_t* dh = nullptr; };
 int kzv_head_ce(const KzvHeadCE& a, hipStream_t s);
 #define KZV_PACK_MAX_JOBS (12 * KZV_DECODE_FUSED_MAX_LAYERS + 4)
 // one input-gradient GEMM of the decoder on the row-panel scheme (decoder_chain.hip): out[M, N] = a[M, K] . (packed W^T)  [+ resid | * aux]

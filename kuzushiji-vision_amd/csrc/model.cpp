@@ -88,7 +88,8 @@ struct kzv_model {
     // cross-attention K/V re-laid out for the generation steps ([layer][K|V][image][head][key][64]); rebuilt when the encoder ran
     bf16_t* ckv_dec = nullptr; size_t ckv_dec_bytes = 0; bool ckv_dec_ok = false;
     // the decoder's bf16 weights in MFMA fragment order (decode_fused.hip), refreshed after every weight change
-    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false; int64_t head_pack_off = 0, tpack_off = 0;
+    bf16_t* dec_pack = nullptr; bool dec_pack_ok = false; int64_t head_pack_off = 0, tpack_off = 0, head_tpack_off = 0;
+    bool dhln_fused = false;     // the last training forward's head_ce launch already wrote dhln (the LM head's input gradient)
     // graph-replayed decode step (kzv_decode_step_graph): device-side step index + one instantiated graph per cache copy
     int* d_t = nullptr;
     hipGraphExec_t dgraph[3] = {nullptr, nullptr, nullptr};          // one per row table in use: none, rowtab[0], rowtab[1]
@@ -592,8 +593,13 @@ int forward(kzv_model* m, const float* px, const int64_t* labels, float* d_loss,
     // logits never written (decoder_chain.hip head_ce_kernel).  Otherwise the GEMM materialises them and ce_kernel follows.
     if (fused_head) {
         KzvHeadCE hc{m->hd_ln, m->dec_pack + m->head_pack_off, P + m->hbias, labels, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, Md, m->L, T, m->V, (int)m->Vp, c.pad_id};
+        static int fuse_dh = -1;     // the head's input gradient inside the same launch (KZV_HEAD_DGRAD=0: the separate GEMM)
+        if (fuse_dh < 0) { const char* e = getenv("KZV_HEAD_DGRAD"); fuse_dh = e ? atoi(e) : 1; }
+        m->dhln_fused = m->train && fuse_dh && m->w_word.ldt % 8 == 0;
+        if (m->dhln_fused) { hc.wpt = m->dec_pack + m->head_tpack_off; hc.dh = m->dhln; }
         KZV_TRY(kzv_head_ce(hc, s));
     } else {
+        m->dhln_fused = false;
         KZV_TRY(gemm(m->hd_ln, Hd, m->w_word, false, Md, m->Vp, Hd, m->V, P + m->hbias, m->logits, m->Vp, KZV_EPI_F32, s));
         KZV_TRY(kzv_ce_fwd_bwd(m->logits, m->Vp, labels, m->L, B, T, m->V, c.pad_id, m->count, m->loss_acc, m->train ? m->dlogits : nullptr, s));
     }
@@ -634,7 +640,7 @@ int backward_decoder(kzv_model* m, hipStream_t s) {
     auto tp = [&](int layer, int64_t off) { return (const bf16_t*)(m->dec_pack + m->tpack_off + perd * layer + off); };
     // ---- CE -> LM head ------------------------------------------------------------------------------
     KZV_TRY(wgrad_batch(m, CLS_MISC, s, m->dlogits, m->Vp, m->hd_ln, Hd, G + m->word, Md, m->Vp, Hd, m->V, G + m->hbias));
-    KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
+    if (!m->dhln_fused) KZV_TRY(gemm(m->dlogits, m->Vp, m->w_word, true, Md, Hd, m->Vp, Hd, nullptr, m->dhln, Hd, KZV_EPI_BF16, s));
     KZV_TRY(kzv_ln_bwd_ex(m->dhln, 0, m->hd_gelu, m->hd_st, P + m->hln_w, m->dsum_d, 0, G + m->hln_w, G + m->hln_b, Md, Hd, 1, 0, 0.f, 0, s));
     KZV_TRY(kzv_cast_drop_colsum(m->dsum_d, m->dy_d, G + m->hd_b, Md, Hd, 0.f, 0, s, m->hd_pre));
     const bf16_t* x_last_h = m->Ld ? m->da[m->Ld - 1].x3h : m->xd0h;
@@ -1166,7 +1172,7 @@ int ensure_dec_pack(kzv_model* m, hipStream_t s) {
     const int64_t vq = (m->V + 255) / 256 * 256;                 // the tied LM-head weight in 256-row chunks, zero rows beyond the vocabulary (head_ce_kernel)
     m->head_pack_off = per * m->Ld + Hd * Hd;
     if (!m->dec_pack) {
-        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(2 * (per * m->Ld + Hd * Hd) + vq * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
+        if (hipMalloc((void**)&m->dec_pack, sizeof(bf16_t) * (size_t)(2 * (per * m->Ld + Hd * Hd) + 2 * vq * Hd)) != hipSuccess) return kzv_fail(KZV_E_HIP, "decode: weight pack allocation");
         for (int i = 0; i < 3; ++i) if (m->dgraph[i]) { (void)hipGraphExecDestroy(m->dgraph[i]); m->dgraph[i] = nullptr; }
     }
     std::vector<KzvPackJob> jobs;
@@ -1193,6 +1199,10 @@ int ensure_dec_pack(kzv_model* m, hipStream_t s) {
         jobs.push_back({m->w_dfc2[i].wt, o, (int)Fd, (int)Hd});
     }
     jobs.push_back({m->w_hd.wt, m->dec_pack + m->tpack_off + per * m->Ld, (int)Hd, (int)Hd});
+    // the tied LM-head weight transposed ([hidden, vocabulary]: the B operand of the head's input gradient inside head_ce_kernel), columns
+    // beyond the padded vocabulary as zeros
+    m->head_tpack_off = m->tpack_off + per * m->Ld + Hd * Hd;
+    jobs.push_back({m->w_word.wt, m->dec_pack + m->head_tpack_off, (int)Hd, (int)vq, (int)Hd, (int)m->w_word.ldt, (int)m->Vp});
     KZV_TRY(kzv_pack_frag_multi(jobs.data(), (int)jobs.size(), s));
     m->dec_pack_ok = true;
     return KZV_OK;
