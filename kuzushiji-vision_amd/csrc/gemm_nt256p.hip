@@ -441,7 +441,10 @@ int kzv_nt_strip() {
 namespace {
 int nt256p_min_tiles() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("KZV_NT256P_MIN_TILES"); v = e ? atoi(e) : 384; }
+    // 150 since the end of round 4 (384 before): the two 160-tile projections between encoder and decoder (41k x 256 x 768 forward, x 3072 input
+    // gradient) and the decoder's 180-tile shapes run faster on fewer than 256 persistent workgroups than on the 128 x 128 kernel: step
+    // 30.65 -> 30.58 ms, family +0.002 over five same-box alternations
+    if (v < 0) { const char* e = getenv("KZV_NT256P_MIN_TILES"); v = e ? atoi(e) : 150; }
     return v;
 }
 int device_cus() {
