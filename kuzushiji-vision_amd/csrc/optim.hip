@@ -52,8 +52,11 @@ __global__ __launch_bounds__(256) void clip_step_kernel(float* __restrict__ p, f
     const float ylr = s.lr_t * (s.beta1 * (1.f - s.ckp1) - 1.f);
     const float inv_bc2 = 1.f / s.bias_correction2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 P = ((float4*)p)[i], Z = ((float4*)z)[i], V = ((float4*)v)[i];
-        const float4 G4 = ((const float4*)g)[i];
+        // z, v and the gradient are touched once per step: streaming loads / stores (the parameters stay plain: the weight casts read them next);
+        // step 30.26 -> 30.20 ms over four same-box alternations
+        auto ntl = [](const float* q, int64_t i) { const f32x4 t = __builtin_nontemporal_load((const f32x4*)q + i); return make_float4(t[0], t[1], t[2], t[3]); };
+        float4 P = ((float4*)p)[i], Z = ntl(z, i), V = ntl(v, i);
+        const float4 G4 = ntl(g, i);
         float* pp = (float*)&P; float* zz = (float*)&Z; float* vv = (float*)&V; const float* gg = (const float*)&G4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(256) void clip_step_kernel(float* __restrict__ p, f
             pp[r] = y;
             zz[r] -= s.lr_t * gn;
         }
-        ((float4*)p)[i] = P; ((float4*)z)[i] = Z; ((float4*)v)[i] = V;
+        ((float4*)p)[i] = P;
+        __builtin_nontemporal_store((f32x4){Z.x, Z.y, Z.z, Z.w}, (f32x4*)z + i); __builtin_nontemporal_store((f32x4){V.x, V.y, V.z, V.w}, (f32x4*)v + i);
         if (EMA) {
             float4 E = ((float4*)ema)[i];
             E.x += ema_w * (P.x - E.x); E.y += ema_w * (P.y - E.y); E.z += ema_w * (P.z - E.z); E.w += ema_w * (P.w - E.w);
