@@ -16,6 +16,9 @@
 //           dK^T, dV^T for them in registers across the query sweep (no cross-workgroup reduction);
 //           S and dP are computed with the key on the lane so their accumulators are the B operands of
 //           dV^T += dO^T.P and dK^T += Q^T.dS; only dS crosses LDS (bf16, 32-query slab) for dQ.
+// Q / K / V / O / dO are read once per (batch, head): every LDS-DMA of this unit carries the streaming hint (kzv_common.h KZV_GLDS_NT):
+// attention forward 1.044 -> 1.012 ms per step, backward 2.63 -> 2.54, four same-box alternations (round 4)
+#define KZV_GLDS_NT
 #include "kzv_common.h"
 #include "../../include/kzv.h"
 #include "kzv_host.h"

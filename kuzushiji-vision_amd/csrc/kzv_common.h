@@ -182,8 +182,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
+// (KZV_GLDS_NT, defined by a translation unit before this header: every LDS-DMA of that unit carries the streaming hint)
+#ifdef KZV_GLDS_NT
+#define KZV_GLDS_AUX 2
+#define KZV_GLDS_SFX " nt"
+#else
+#define KZV_GLDS_AUX 0
+#define KZV_GLDS_SFX ""
+#endif
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const KZV_GLB void*)g, (KZV_LDS void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const KZV_GLB void*)g, (KZV_LDS void*)lds_wave_base, 16, 0, KZV_GLDS_AUX);
 }
 // Same LDS-DMA issued from inline asm: invisible to hipcc's waitcnt pass, so the compiler does not put a
 // vmcnt(0) in front of later LDS reads it cannot disambiguate (it does for ds_read_b64_tr_b16 after a
@@ -192,26 +200,26 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 __device__ __forceinline__ void glds16_asm(const void* g, void* lds_wave_base) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" KZV_GLDS_SFX "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 // Same, leaving M0 clobbered: only for kernels that issue EVERY LDS-DMA through this helper (no builtin LDS-DMA,
 // whose M0 the compiler tracks), e.g. gemm_tn.
 __device__ __forceinline__ void glds16_asm_m0(const void* g, void* lds_wave_base) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" KZV_GLDS_SFX : : "v"(g), "s"(dst) : "memory");
 }
 // Same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no 64-bit address registers per lane)
 __device__ __forceinline__ void glds16_asm_soff(const void* sbase, unsigned voff, void* lds_wave_base) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" KZV_GLDS_SFX "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
 }
 // the SGPR-base form with M0 left clobbered (same condition as glds16_asm_m0)
 __device__ __forceinline__ void glds16_asm_soff_m0(const void* sbase, unsigned voff, void* lds_wave_base) {
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__SIZE_TYPE__)((KZV_LDS char*)lds_wave_base));
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" KZV_GLDS_SFX : : "v"(voff), "s"(sbase), "s"(dst) : "memory");
 }
 __device__ __forceinline__ bf16x4 lds_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((KZV_LDS bf16x4*)p);
