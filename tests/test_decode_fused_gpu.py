@@ -125,3 +125,25 @@ def test_generate_in_both_modes(tmp_path):
         agree = float((got[0][:, :w] == got[1][:, :w]).float().mean())
         print(f"beams {beams}: token agreement {agree:.3f}")
         assert agree > 0.9                                          # untrained, nearly flat logits: rare argmax ties may flip
+
+
+def test_generation_with_more_images_than_compute_units(tmp_path):
+    """600 images in ONE generate call (one workgroup per image in decode_fused.hip: 600 workgroups on 256 CUs, two rounds and slower loads)
+    against the same images in batches of 100, greedy and beam-4: token for token.  (Added with the decoder-chain fix of round 4: a wait that
+    hipcc sized too leniently only showed once a launch had more workgroups than CUs; tests/test_decoder_chain_gpu.py.)"""
+    import dataclasses
+
+    import torch
+
+    from kzv.config import tiny_config
+    from kzv.data import build_decoder_dir, synthetic_batch
+    from kzv.model import TrOCRModel
+    cfg = dataclasses.replace(tiny_config(), dec_hidden=256, dec_heads=4, dec_ffn=768, dec_layers=6)
+    m = TrOCRModel(cfg.encoder_config_dict(), build_decoder_dir(str(tmp_path / "dec"), cfg), init_seed=4, load_tokenizer=False)
+    m.eval()
+    px, _ = synthetic_batch(cfg, 600, 20, seed=3)
+    px = torch.from_numpy(px).cuda()
+    for beams in (1, 4):
+        whole = m.generate(px, max_length=24, num_beams=beams)
+        parts = torch.cat([m.generate(px[i:i + 100], max_length=24, num_beams=beams) for i in range(0, 600, 100)])
+        assert whole.shape == parts.shape and torch.equal(whole, parts), f"beams {beams}: {int((whole != parts).any(1).sum())} sequences differ"
